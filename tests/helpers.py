@@ -1,0 +1,39 @@
+"""Shared recipes for the parity tests (inputs are regenerated from seeds, outputs come from
+tests/golden/*.npz written by tools/make_golden.py from the imported reference)."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def synth_params(V, H, C, seed):
+    # same recipe as tools/make_golden.py::synth_params (legacy MT19937 streams are version-stable)
+    rs = np.random.RandomState(seed)
+    W = (rs.standard_normal((V, H)) * 0.1).astype(np.float32)
+    b = (rs.standard_normal(V) * 0.2).astype(np.float32)
+    d = (rs.standard_normal(H) * 0.2).astype(np.float32)
+    U = (rs.standard_normal((C, H)) * 0.3).astype(np.float32)
+    c = (rs.standard_normal(C) * 0.1).astype(np.float32)
+    return W, b, d, U, c
+
+
+def synth_inputs(B, V, H, C, seed):
+    rs = np.random.RandomState(seed + 1000)
+    v_bin = (rs.random_sample((B, V)) < 0.3).astype(np.float32)
+    x_grey = rs.random_sample((B, V)).astype(np.float32) * (rs.random_sample((B, V)) < 0.4)
+    x_grey = x_grey.astype(np.float32)
+    h_bin = (rs.random_sample((B, H)) < 0.5).astype(np.float32)
+    labels = rs.randint(0, C, size=B).astype(np.int64)
+    y1h = np.eye(C, dtype=np.float32)[labels]
+    return v_bin, x_grey, h_bin, labels, y1h
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-30))
