@@ -1,0 +1,202 @@
+/*
+ * qbm_hip.h -- C ABI of libqbm_hip.so: the MI355X (gfx950) Gibbs-sampling / contrastive-divergence
+ * hot path of Mark-Seebode/QBM-Image-Classification behind plain pointers and sizes.
+ *
+ * The reference has no FFI: its boundaries are Python duck types.  Each entry point
+ * below names the reference interface it sits under (file:line relative to the reference root); the
+ * Python mirror of those interfaces lives in qbm_image_classification_amd/ and binds these symbols
+ * with ctypes (INTEGRATION.md shows the stub a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory (e.g. torch tensor .data_ptr());
+ *     nothing is allocated, freed or cached inside the library, there is no global state;
+ *   - all matrices are dense row-major float32 unless stated otherwise;
+ *   - `stream` is a hipStream_t (NULL = the default stream); every call only enqueues work on it,
+ *     never synchronises, and is legal inside hipStreamBeginCapture/EndCapture;
+ *   - return value: QBM_OK (0) or a negative QBM_ERR_* code; qbm_last_error() returns the message of
+ *     the calling thread's last failure;
+ *   - RNG: Philox4x32-10, key = seed, counter = (col>>2, row0+row, offset lo, offset hi); the caller
+ *     advances `offset` per draw.  `row0` is the global index of the first local row, so results
+ *     do not depend on how a minibatch is sharded over GPUs.
+ *   - numerics: DESIGN.md "Numerical contract" (K-quartered fp32 FMA chains on the MFMA pipe).
+ */
+#ifndef QBM_HIP_H
+#define QBM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QBM_ABI_VERSION 1
+#define QBM_MAX_CLASSES 32
+#define QBM_MAX_QUBO_VARS 1024
+
+#define QBM_OK 0
+#define QBM_ERR_ARG (-1) /* bad dimension / null pointer */
+#define QBM_ERR_HIP (-2) /* a HIP runtime call or kernel launch failed */
+
+#if defined(__GNUC__)
+#define QBM_API __attribute__((visibility("default")))
+#else
+#define QBM_API
+#endif
+
+/* ClassificationRBM state, src/ClassificationRBM.py:26-30:
+ * weights[V,H], visible_bias[V], hidden_bias[H], class_weights[C,H], class_bias[C]. */
+typedef struct {
+    float* W;
+    float* b;
+    float* d;
+    float* U;
+    float* c;
+    int V, H, C;
+} qbm_rbm_params;
+
+/* gradient blocks (the reference's *_grad attributes, src/ClassificationRBM.py:130-138); any pointer
+ * may be NULL = "not wanted" (update then treats it as zero, like visible_bias_grad = 0 at :138). */
+typedef struct {
+    float* gW;
+    float* gb;
+    float* gd;
+    float* gU;
+    float* gc;
+} qbm_rbm_grads;
+
+QBM_API int qbm_abi_version(void);
+QBM_API const char* qbm_last_error(void);
+
+/* ---- RBM conditionals --------------------------------------------------------------------- */
+
+/* ClassificationRBM.sample_hidden, src/ClassificationRBM.py:43-47: p_h = sigma(v.W + d + y.U).
+ * v[B,V], y1hot[B,C] (NULL = no class term); outputs p_h[B,H] (probabilities, what the reference
+ * returns) and/or h_sample[B,H] = (p_h > u) in {0,1} (either may be NULL, not both). */
+QBM_API int qbm_rbm_sample_hidden(const qbm_rbm_params* P, const float* v, const float* y1hot, int B,
+                                  float* p_h, float* h_sample, uint64_t seed, uint64_t offset, uint32_t row0,
+                                  void* stream);
+
+/* x.W + d, the `precomputed_factor` of src/ClassificationRBM.py:65 and :106.  pre[B,H]. */
+QBM_API int qbm_rbm_hidden_preact(const qbm_rbm_params* P, const float* x, int B, float* pre, void* stream);
+
+/* ClassificationRBM.sample_visible, src/ClassificationRBM.py:49-52: p_v = sigma(h.W^T + b). */
+QBM_API int qbm_rbm_sample_visible(const qbm_rbm_params* P, const float* h, int B, float* p_v, float* v_sample,
+                                   uint64_t seed, uint64_t offset, uint32_t row0, void* stream);
+
+/* ClassificationRBM.sample_class, src/ClassificationRBM.py:54-60: exp(h.U^T + c), L1-normalised.
+ * p_y[B,C] and/or a categorical one-hot draw y1hot[B,C]. */
+QBM_API int qbm_rbm_sample_class(const qbm_rbm_params* P, const float* h, int B, float* p_y, float* y1hot,
+                                 uint64_t seed, uint64_t offset, uint32_t row0, void* stream);
+
+/* ClassificationRBM.sample_class_given_x, src/ClassificationRBM.py:62-86 (free-energy evaluation).
+ * pre_ws[B,H] workspace (receives x.W + d); neg_free_energy[B,C] = -F(x,y) (may be NULL);
+ * p_y_given_x[B,C] (may be NULL). */
+QBM_API int qbm_rbm_free_energy(const qbm_rbm_params* P, const float* x, int B, float* pre_ws,
+                                float* neg_free_energy, float* p_y_given_x, void* stream);
+
+/* ---- gradients and update ----------------------------------------------------------------- */
+
+/* Elementwise stage of ClassificationRBM.discriminative_training, src/ClassificationRBM.py:106-126:
+ * from pre[B,H], p_y[B,C], labels[B] (int32): pos[B,H] = o_{label}, neg[B,H] = sum_c o_c p_c,
+ * onehot[B,C] (may be NULL). */
+QBM_API int qbm_rbm_disc_terms(const qbm_rbm_params* P, const float* pre, const float* p_y, const int32_t* labels,
+                               int B, float* pos, float* neg, float* onehot, void* stream);
+
+/* Class part of the discriminative gradient, src/ClassificationRBM.py:113-115,125,132,136:
+ * gU[C,H] (in: onehot^T.pos, from qbm_rbm_two_phase_grad) -= sum_i o_ic p_ic;  gc[C] = sum(onehot - p). */
+QBM_API int qbm_rbm_disc_class_grad(const qbm_rbm_params* P, const float* pre, const float* p_y,
+                                    const int32_t* labels, int B, float* gU, float* gc, void* stream);
+
+/* Two-phase batch gradient (CD-k: SURVEY.md 8.A-7; discriminative: src/ClassificationRBM.py:118-138):
+ *   gW = A0^T.P0 - A1^T.P1,  gU = Y0^T.P0 - Y1^T.P1,  gd = colsum(P0) - colsum(P1),
+ *   gb = colsum(A0) - colsum(A1),  gc = colsum(Y0) - colsum(Y1)
+ * A*[B,V], Y*[B,C] (NULL = zeros), P*[B,H].  Outputs as selected by the non-NULL fields of G.
+ * W_fused non-NULL: additionally W += factor*gW*lr/batch_size in the same pass
+ * (src/ClassificationRBM.py:90); gW itself may then be NULL. */
+QBM_API int qbm_rbm_two_phase_grad(int V, int H, int C, int B, const float* A0, const float* Y0, const float* P0,
+                                   const float* A1, const float* Y1, const float* P1, const qbm_rbm_grads* G,
+                                   float* W_fused, float lr, float factor, float batch_size, void* stream);
+
+/* ClassificationRBM.update_weights, src/ClassificationRBM.py:88-99:
+ * theta += factor*grad*lr/batch_size; b, d, c -= sparse_constant.  G->gW == NULL skips W (already
+ * updated by the fused gradient pass). */
+QBM_API int qbm_rbm_update(const qbm_rbm_params* P, const qbm_rbm_grads* G, float lr, float factor,
+                           float batch_size, float sparse_constant, void* stream);
+
+/* ---- composites: launch sequences on `stream` (graph-capturable) ---------------------------- */
+
+/* caller-owned scratch of one CD-k / PCD step */
+typedef struct {
+    float* ph0;   /* [B,H] positive-phase hidden probabilities */
+    float* h;     /* [B,H] current hidden sample */
+    float* vk;    /* [B,V] */
+    float* yk;    /* [B,C] */
+    float* phk;   /* [B,H] */
+} qbm_rbm_cd_workspace;
+
+/* k-step block-Gibbs chain (declared, never implemented in the reference:
+ * src/ClassificationRBM.py:19, :179-182).  Draw ids: h_0 -> offset; t = 1..k: v_t -> offset+3t-2,
+ * y_t -> offset+3t-1, h_t -> offset+3t.  chain_v/chain_y non-NULL = persistent chains (PCD): the
+ * negative chain starts from them and they receive (v_k, y_k). */
+QBM_API int qbm_rbm_cd_chain(const qbm_rbm_params* P, const float* v0, const float* y0, int B, int k,
+                             uint64_t seed, uint64_t offset, uint32_t row0, float* chain_v, float* chain_y,
+                             const qbm_rbm_cd_workspace* ws, void* stream);
+
+/* chain + gradient (+ update).  G: gradient blocks (data-parallel path: all-reduce them, then call
+ * qbm_rbm_update).  fuse_update != 0: single-GPU path, W is updated inside the gradient pass and the
+ * remaining blocks by one update launch; G must still provide gb, gd, gU, gc. */
+QBM_API int qbm_rbm_cd_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const float* v0, const float* y0,
+                            int B, int k, uint64_t seed, uint64_t offset, uint32_t row0, float* chain_v,
+                            float* chain_y, const qbm_rbm_cd_workspace* ws, int fuse_update, float lr,
+                            float factor, float batch_size, float sparse_constant, void* stream);
+
+/* caller-owned scratch of one discriminative step */
+typedef struct {
+    float* pre;    /* [B,H] */
+    float* pos;    /* [B,H] */
+    float* neg;    /* [B,H] */
+    float* onehot; /* [B,C] */
+} qbm_rbm_disc_workspace;
+
+/* ClassificationRBM.discriminative_training, src/ClassificationRBM.py:101-146 without the host-side
+ * loss: p_y[B,C] = p(y|x) before the update (returned third by the reference), neg_free_energy[B,C]
+ * optional.  fuse_update as above; apply_update == 0 leaves the parameters untouched (gradients only). */
+QBM_API int qbm_rbm_disc_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const float* x,
+                              const int32_t* labels, int B, float* p_y, float* neg_free_energy,
+                              const qbm_rbm_disc_workspace* ws, int apply_update, int fuse_update, float lr,
+                              float factor, float batch_size, float sparse_constant, void* stream);
+
+/* ---- Disc_QBM: QUBO sampler ------------------------------------------------------------------ */
+
+/* HIP replacement of the annealer behind Disc_QBM.get_samples / get_samples_batch
+ * (src/model/faster_dqbm.py:571-684, :961-969; sample_sa :299-306 -> dwave-neal) and behind the
+ * sample_Q protocol (src/qubo/sampler.py:26-33).  Energy E(s) = sum_i lin_i s_i + sum_{i<j} J_ij s_i s_j
+ * (the QUBO s^T Q s with Q upper-triangular: lin = diag(Q), J = Q_offdiag + Q_offdiag^T), minimised.
+ *   lin[B,n]  per-image linear fields;  J[n,n] symmetric couplings with zero diagonal, shared by the
+ *   whole batch;  R reads (independent chains) per image;  `sweeps` sequential heat-bath sweeps with a
+ *   geometric inverse-temperature schedule beta0 -> beta1 (beta0 == beta1: plain Gibbs sampling).
+ * Outputs: states[B,R,n] uint8 in {0,1} (column j = variable j, the reference's sample order) and,
+ * if non-NULL, mean[B,n] = average over reads (np.average(np_samples, axis=0), faster_dqbm.py:780).
+ * Draw ids: start state -> offset, sweep t -> offset + t; Philox row = b*R + r, col = variable. */
+QBM_API int qbm_qubo_gibbs(const float* lin, const float* J, int B, int R, int n, int sweeps, float beta0,
+                           float beta1, uint64_t seed, uint64_t offset, uint8_t* states, float* mean,
+                           void* stream);
+
+/* x-dependent part of Disc_QBM.create_qubo_matrix_from (src/model/faster_dqbm.py:225-284), float64:
+ *   labels != NULL (clamped, n = H):   lin_j = (b_h[j] + label*W_vh[0,j] + sum_k x_k W_vh[1+k,j]) / beta_eff
+ *   labels == NULL (unclamped, n = 1+H): lin_0 = (b_o + sum_k x_k W_vo[k]) / beta_eff,
+ *                                        lin_{1+j} = (b_h[j] + sum_k x_k W_vh[1+k,j]) / beta_eff
+ * X[B,D] f64, W_vh[(1+D),H] f64 (row 0 = label row), W_vo[D] f64, b_h[H] f64; lin[B,n] f32. */
+QBM_API int qbm_qbm_linear_fields(const double* X, const int32_t* labels, const double* W_vh, const double* W_vo,
+                                  const double* b_h, double b_o, int B, int D, int H, double beta_eff, float* lin,
+                                  void* stream);
+
+/* ---- test hooks (bit-compare the device math with the oracle) -------------------------------- */
+QBM_API int qbm_test_math(int which, const float* x, float* y, int n, void* stream);
+QBM_API int qbm_test_uniform(uint64_t seed, uint64_t offset, uint32_t row0, int rows, int cols, float* out,
+                             void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QBM_HIP_H */

@@ -1,0 +1,298 @@
+"""ClassificationRBM -- drop-in mirror of the reference's src/ClassificationRBM.py on the HIP path.
+
+Same constructor, public attributes and methods as the reference class (boundary B1);
+every method that does arithmetic forwards to libqbm_hip.so through rbm_ops.HipRbmOps.  Differences,
+all deliberate:
+  * the parameters live on the ROCm device (the reference forces CPU: src/ClassificationRBM.py:21);
+  * `train_rbm(method=...)` also accepts 'generative' and 'hybrid', which the reference declares
+    (rbm_main.py:22-28) but rejects (src/ClassificationRBM.py:181-182): CD-k / PCD as specified in
+    SURVEY.md 8.A-7, built from the reference's own conditionals (:43-60) and update rule (:88-99);
+  * with torch.distributed initialised (one process per GPU, RCCL) a step all-reduces one flat
+    gradient buffer and divides by the global batch size.
+Reference quirks are mirrored on purpose: the loss is CrossEntropyLoss applied
+to probabilities (Q1, :142); roc_auc_score is computed on hard predictions (Q4, :280).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .rbm_ops import GradSet, HipRbmOps, ParamSet
+
+
+def _dist_ready():
+    import torch.distributed as dist
+
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class ClassificationRBM:
+    # reference signature: src/ClassificationRBM.py:12-13 (+ keyword-only extensions)
+    def __init__(self, num_visible, num_hidden, k, num_classes=2, learning_rate=0.05, sparse_constant=0.00,
+                 use_cuda=False, seed=42, *, persistent=False, device=None, ops=None, data_parallel=None,
+                 keep_grads=False):
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        self.seed = seed
+        self.num_visible = num_visible
+        self.num_hidden = num_hidden
+        self.k = k
+        self.learning_rate = learning_rate
+        self.num_classes = num_classes
+        self.loss = torch.nn.CrossEntropyLoss()
+        self.sparse_constant = sparse_constant
+        self.persistent = persistent
+        # keep_grads=True materialises weights_grad like the reference; False fuses the W update into the
+        # gradient pass (single-GPU path only; the data-parallel path always materialises for the all-reduce)
+        self.keep_grads = keep_grads
+
+        if ops is None:
+            if device is None:
+                device = f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cuda:0"
+            ops = HipRbmOps(device)  # raises if the HIP library or the GPU is missing: no CPU fallback
+        self.ops = ops
+        self.device = ops.device
+        self.use_cuda = self.device.type == "cuda"
+
+        # same draw order as the reference (:26-30): one torch.randn(V, H) right after manual_seed
+        self.weights = (torch.randn(num_visible, num_hidden) * 0.1).to(self.device)
+        self.visible_bias = (torch.ones(num_visible) * 0.5).to(self.device)
+        self.hidden_bias = torch.zeros(num_hidden).to(self.device)
+        self.class_bias = torch.zeros(num_classes).to(self.device)
+        self.class_weights = (torch.zeros(num_classes, num_hidden) * 0.5).to(self.device)
+
+        self._grads = GradSet(num_visible, num_hidden, num_classes, self.device)
+        self.weights_grad = self._grads.gW
+        self.visible_bias_grad = 0
+        self.hidden_bias_grad = self._grads.gd
+        self.class_bias_grad = self._grads.gc
+        self.class_weights_grad = self._grads.gU
+
+        self.acc_per_epoch_list = []
+        self.auc_per_epoch_list = []
+
+        self.data_parallel = _dist_ready() if data_parallel is None else bool(data_parallel)
+        self._draw_offset = 0     # Philox draw id, advanced by every sampling call
+        self._rows_seen = 0       # global row counter (row0 of the next minibatch)
+        self._chain_v = None      # persistent chains (PCD)
+        self._chain_y = None
+
+    # ------------------------------------------------------------------------------------------
+    def _params(self) -> ParamSet:
+        # rebuilt per call so that user code may rebind the public attributes, as with the reference
+        return ParamSet(self.weights, self.visible_bias, self.hidden_bias, self.class_weights, self.class_bias)
+
+    def _next_offset(self, n=1):
+        o = self._draw_offset
+        self._draw_offset += n
+        return o
+
+    # ---- reference API: conditionals (return probabilities, like the reference) ----------------
+    def sample_hidden(self, visible_activations, class_activations):
+        """src/ClassificationRBM.py:43-47"""
+        p, _ = self.ops.sample_hidden(self._params(), visible_activations, class_activations)
+        return p
+
+    def sample_visible(self, hidden_activations):
+        """src/ClassificationRBM.py:49-52"""
+        p, _ = self.ops.sample_visible(self._params(), hidden_activations)
+        return p
+
+    def sample_class(self, hidden_activations):
+        """src/ClassificationRBM.py:54-60"""
+        p, _ = self.ops.sample_class(self._params(), hidden_activations)
+        return p
+
+    def sample_class_given_x(self, input_data):
+        """src/ClassificationRBM.py:62-86 (p(y|x) from free energies)"""
+        _, p = self.ops.free_energy(self._params(), input_data)
+        return p
+
+    def free_energy(self, input_data):
+        """-F(x, y) for every class: the intermediate of src/ClassificationRBM.py:68-74."""
+        nf, _ = self.ops.free_energy(self._params(), input_data)
+        return nf
+
+    # ---- Bernoulli / categorical draws (build-defined) ------------------------
+    def draw_hidden(self, v, y, row0=0):
+        return self.ops.sample_hidden(self._params(), v, y, self.seed, self._next_offset(), row0, True, True)
+
+    def draw_visible(self, h, row0=0):
+        return self.ops.sample_visible(self._params(), h, self.seed, self._next_offset(), row0, True, True)
+
+    def draw_class(self, h, row0=0):
+        return self.ops.sample_class(self._params(), h, self.seed, self._next_offset(), row0, True, True)
+
+    # ---- reference API: update + training rules ------------------------------------------------
+    def update_weights(self, batch_size, factor=1):
+        """src/ClassificationRBM.py:88-99, applied to the *_grad buffers."""
+        with_gb = not (isinstance(self.visible_bias_grad, (int, float)) and self.visible_bias_grad == 0)
+        self.ops.update(self._params(), self._grads, float(self.learning_rate), float(factor), float(batch_size),
+                        float(self.sparse_constant), with_gb=with_gb)
+
+    def _allreduce_grads(self, local_rows):
+        import torch.distributed as dist
+
+        self._grads.count.fill_(float(local_rows))
+        dist.all_reduce(self._grads.flat, op=dist.ReduceOp.SUM)  # one RCCL collective per step
+        return float(self._grads.count.item())
+
+    def discriminative_training(self, input_data, class_label, factor=1):
+        """src/ClassificationRBM.py:101-146 -> (error, predicted, class_probabilities)"""
+        batch_size = input_data.size(0)
+        P = self._params()
+        self.visible_bias_grad = 0  # :138
+        lr, sp = float(self.learning_rate), float(self.sparse_constant)
+        if self.data_parallel:
+            p = self.ops.disc_step(P, self._grads, input_data, class_label, False, False, lr, float(factor),
+                                   float(batch_size), sp)
+            global_rows = self._allreduce_grads(batch_size)
+            self.ops.update(P, self._grads, lr, float(factor), global_rows, sp, with_gb=False)
+        else:
+            p = self.ops.disc_step(P, self._grads, input_data, class_label, True, not self.keep_grads, lr,
+                                   float(factor), float(batch_size), sp)
+        labels_dev = torch.as_tensor(class_label).to(self.device).long()
+        error = self.loss(p, labels_dev)  # on probabilities, as the reference does (:142)
+        _, predicted = torch.max(p, 1)
+        return error, predicted, p
+
+    def contrastive_divergence_training(self, input_data, class_label, factor=1):
+        """CD-k (or PCD when persistent=True) generative step, SURVEY.md 8.A-7:
+        dW = v0^T p(h0) - vk^T p(hk), db = sum(v0 - vk), dd = sum(p(h0) - p(hk)), dU = y0^T p(h0) - yk^T p(hk),
+        dc = sum(y0 - yk); update rule of src/ClassificationRBM.py:88-99."""
+        batch_size = input_data.size(0)
+        P = self._params()
+        labels_dev = torch.as_tensor(class_label).to(self.device).long()
+        y0 = torch.nn.functional.one_hot(labels_dev, num_classes=self.num_classes).float()
+        v0 = torch.as_tensor(input_data).to(self.device, torch.float32)
+        lr, sp = float(self.learning_rate), float(self.sparse_constant)
+        rank_rows = 0
+        if self.data_parallel:
+            import torch.distributed as dist
+
+            rank_rows = dist.get_rank() * batch_size
+        row0 = (self._rows_seen + rank_rows) & 0xFFFFFFFF
+        offset = self._next_offset(3 * self.k + 1)
+        if self.persistent and (self._chain_v is None or self._chain_v.shape[0] != batch_size):
+            self._chain_v = v0.clone()
+            self._chain_y = y0.clone()
+        cv = self._chain_v if self.persistent else None
+        cy = self._chain_y if self.persistent else None
+        self.visible_bias_grad = self._grads.gb
+        if self.data_parallel:
+            self.ops.cd_step(P, self._grads, v0, y0, self.k, self.seed, offset, row0, cv, cy, False, lr,
+                             float(factor), float(batch_size), sp)
+            global_rows = self._allreduce_grads(batch_size)
+            self.ops.update(P, self._grads, lr, float(factor), global_rows, sp)
+            self._rows_seen += int(global_rows)
+        else:
+            if self.keep_grads:
+                self.ops.cd_step(P, self._grads, v0, y0, self.k, self.seed, offset, row0, cv, cy, False, lr,
+                                 float(factor), float(batch_size), sp)
+                self.ops.update(P, self._grads, lr, float(factor), float(batch_size), sp)
+            else:  # W update fused into the gradient pass, remaining blocks by one update launch
+                self.ops.cd_step(P, self._grads, v0, y0, self.k, self.seed, offset, row0, cv, cy, True, lr,
+                                 float(factor), float(batch_size), sp)
+            self._rows_seen += batch_size
+        return None
+
+    def _sigmoid(self, x):
+        """src/ClassificationRBM.py:148-149 (host helper kept for API parity)"""
+        return 1 / (1 + torch.exp(-x))
+
+    def _random_probabilities(self, num):
+        """src/ClassificationRBM.py:151-157: uniforms in [0,1); here from the device Philox stream."""
+        return self.ops.uniform(self.seed, self._next_offset(), 0, 1, int(num)).view(-1)
+
+    # ---- reference API: loops ------------------------------------------------------------------
+    def train_rbm(self, train_loader, epochs, cuda=False, validation_loader=None, test_loader=None,
+                  method='discriminative', generative_factor=None, discriminative_factor=1):
+        """src/ClassificationRBM.py:159-205 -> (loss_list, model, nll_list)"""
+        print('Training RBM...')
+        loss_list = []
+        nll_list = []
+        best_validation_model = None
+        for epoch in range(epochs):
+            epoch_error = 0.0
+            epoch_nll = 0.0
+            for batch, labels in train_loader:
+                batch = batch.view(len(batch), self.num_visible)  # flatten input data (:173)
+                batch = batch.to(self.device, torch.float32)
+                labels = labels.to(self.device)
+                if method == 'discriminative':
+                    batch_error, _, class_probs = self.discriminative_training(batch, labels, discriminative_factor)
+                elif method == 'generative':
+                    self.contrastive_divergence_training(batch, labels, 1 if generative_factor is None else generative_factor)
+                    class_probs = self.sample_class_given_x(batch)
+                    batch_error = self.loss(class_probs, labels.long())
+                elif method == 'hybrid':
+                    # Larochelle & Bengio hybrid objective: discriminative step + generative_factor * CD-k step
+                    batch_error, _, class_probs = self.discriminative_training(batch, labels, discriminative_factor)
+                    self.contrastive_divergence_training(batch, labels, 0.01 if generative_factor is None else generative_factor)
+                else:
+                    raise NotImplementedError(method)
+
+                epoch_error += batch_error.item()
+                # NLL of the batch (:188-191)
+                log_probs = torch.log(class_probs + 1e-8)
+                nll = -log_probs[torch.arange(batch.size(0), device=self.device), labels.long()]
+                epoch_nll += nll.mean().item()
+
+            loss_list.append(epoch_error / len(train_loader))
+            nll_list.append(epoch_nll / len(train_loader))
+
+            if test_loader is not None:
+                acc, auc = self.run_test_set(test_loader)
+                self.acc_per_epoch_list.append(acc)
+                self.auc_per_epoch_list.append(auc)
+            print(f'Epoch {epoch} | Error: {epoch_error / len(train_loader):.4f} | NLL: {epoch_nll / len(train_loader):.4f}')
+            best_validation_model = self
+
+        return loss_list, best_validation_model, nll_list
+
+    def test_rbm_model(self, rbm_model, test_loader, args):
+        """src/ClassificationRBM.py:207-228"""
+        correct = 0
+        total = 0
+        for batch, labels in test_loader:
+            batch = batch.view(len(batch), args.visible_units)
+            predicted_probabilities = rbm_model.sample_class_given_x(batch)
+            _, predicted = torch.max(predicted_probabilities, 1)
+            total += labels.size(0)
+            correct += (predicted.cpu() == labels.cpu()).sum().item()
+        print('Accuracy of the network on the test images: %d %%' % (100 * correct / total))
+        return correct / total
+
+    def get_device(self, use_gpu: bool = True) -> torch.device:
+        """src/ClassificationRBM.py:230-249 returns CPU unconditionally; tensors handed to this class may
+        stay on the CPU (they are staged to the GPU per call), so the reference driver's
+        `.to(rbm.get_device(USE_GPU))` keeps working.  The model itself lives on `self.device`."""
+        return torch.device("cpu") if not use_gpu else self.device
+
+    def run_test_set(self, test_loader):
+        """src/ClassificationRBM.py:251-294 -> (accuracy, roc_auc on hard predictions)"""
+        from sklearn.metrics import roc_auc_score
+
+        correct = 0
+        total = 0
+        all_preds = []
+        all_labels = []
+        for batch, labels in test_loader:
+            batch = batch.view(len(batch), self.num_visible)
+            predicted_probabilities = self.sample_class_given_x(batch)
+            _, predicted = torch.max(predicted_probabilities, 1)
+            predicted = predicted.cpu()
+            all_preds.extend(predicted.numpy())
+            all_labels.extend(labels.cpu().numpy())
+            total += labels.size(0)
+            correct += (predicted == labels.cpu()).sum().item()
+        accuracy = correct / total
+        print('Accuracy of the network on the test images: ', accuracy)
+        auc_score = roc_auc_score(all_labels, all_preds)
+        print('AUC Score: %.4f' % auc_score)
+        return accuracy, auc_score
+
+    def get_num_params(self):
+        """src/ClassificationRBM.py:297-307"""
+        return (self.weights.numel() + self.visible_bias.numel() + self.hidden_bias.numel()
+                + self.class_weights.numel() + self.class_bias.numel())

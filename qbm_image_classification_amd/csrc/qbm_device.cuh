@@ -1,0 +1,119 @@
+// qbm_device.cuh -- device-side building blocks for the gfx950 Gibbs / CD kernels.
+//
+// Numerical contract (DESIGN.md "Numerical contract"): IEEE binary32, round-to-nearest-even,
+// compiled with -ffp-contract=off; an FMA happens only where __builtin_fmaf is written or an
+// MFMA instruction is issued.  The same operation sequences are restated independently in
+// oracle/qbm_oracle.c; tests/test_gpu_parity.py checks them bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qbm {
+
+constexpr int kWave = 64;
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11).  key = (seed lo, seed hi);
+// counter = (col >> 2, row, offset lo, offset hi); element (row, col) takes word col & 3.
+// ---------------------------------------------------------------------------------------------
+struct Philox4 {
+    uint32_t w[4];
+};
+
+__device__ __forceinline__ Philox4 philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1,
+                                                  uint32_t c2, uint32_t c3)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0;
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return Philox4{{c0, c1, c2, c3}};
+}
+
+__device__ __forceinline__ float u01(uint32_t w) { return (float)(w >> 8) * 5.9604644775390625e-08f; }
+
+// the four uniforms of columns 4*cg .. 4*cg+3 of one row
+__device__ __forceinline__ f32x4 uniform4(uint64_t seed, uint64_t offset, uint32_t row, uint32_t cg)
+{
+    const Philox4 p = philox4x32_10((uint32_t)seed, (uint32_t)(seed >> 32), cg, row, (uint32_t)offset,
+                                    (uint32_t)(offset >> 32));
+    return f32x4{u01(p.w[0]), u01(p.w[1]), u01(p.w[2]), u01(p.w[3])};
+}
+
+// ---------------------------------------------------------------------------------------------
+// Deterministic fp32 elementary functions (fixed operation sequences).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float det_expf(float x)
+{
+    if (x != x) return x;
+    if (x > 88.72283935546875f) return __builtin_inff();
+    if (x < -87.0f) return 0.0f;
+    const float n = __builtin_rintf(x * 1.44269502162933349609375f);
+    float r = __builtin_fmaf(n, -0.693145751953125f, x);
+    r = __builtin_fmaf(n, -1.428606765330187045037746429443359375e-06f, r);
+    float p = 1.98412701138295233249664306640625e-04f;
+    p = __builtin_fmaf(p, r, 1.38888892251998186111450195312500e-03f);
+    p = __builtin_fmaf(p, r, 8.33333376795053482055664062500000e-03f);
+    p = __builtin_fmaf(p, r, 4.16666679084300994873046875000000e-02f);
+    p = __builtin_fmaf(p, r, 1.66666671633720397949218750000000e-01f);
+    p = __builtin_fmaf(p, r, 0.5f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    const int ni = (int)n;
+    const int h = ni / 2;
+    const float s1 = __uint_as_float((uint32_t)(h + 127) << 23);
+    const float s2 = __uint_as_float((uint32_t)(ni - h + 127) << 23);
+    return (p * s1) * s2;
+}
+
+__device__ __forceinline__ float det_logf(float x)
+{
+    if (x == 0.0f) return -__builtin_inff();
+    if (x == __builtin_inff()) return __builtin_inff();
+    if (!(x > 0.0f)) return __builtin_nanf("");
+    uint32_t ix = __float_as_uint(x);
+    ix += 0x3f800000u - 0x3f3504f3u;
+    const int k = (int)(ix >> 23) - 0x7f;
+    ix = (ix & 0x007fffffu) + 0x3f3504f3u;
+    const float f = __uint_as_float(ix) - 1.0f;
+    const float s = f / (2.0f + f);
+    const float z = s * s;
+    const float w = z * z;
+    const float t1 = w * __builtin_fmaf(w, 0.24279078841f, 0.40000972152f);
+    const float t2 = z * __builtin_fmaf(w, 0.28498786688f, 0.66666662693f);
+    const float R = t2 + t1;
+    const float hfsq = (0.5f * f) * f;
+    const float dk = (float)k;
+    float r = __builtin_fmaf(s, hfsq + R, dk * 9.0580006145e-06f);
+    r = r - hfsq;
+    r = r + f;
+    return __builtin_fmaf(dk, 6.9313812256e-01f, r);
+}
+
+// reference: src/ClassificationRBM.py:148-149  1 / (1 + exp(-x))
+__device__ __forceinline__ float det_sigmoid(float x) { return 1.0f / (1.0f + det_expf(-x)); }
+// reference: src/ClassificationRBM.py:72  log(1 + exp(z)), unstabilised like the reference
+__device__ __forceinline__ float det_softplus(float z) { return det_logf(1.0f + det_expf(z)); }
+
+// ---------------------------------------------------------------------------------------------
+// Wave tree [T]: butterfly p[l] = p[l] + p[l ^ off], off = 32..1.  fp32 addition is commutative,
+// so every lane ends with the same bits.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_butterfly_sum(float p)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, kWave);
+    return p;
+}
+
+// [Q] length of one K quarter: roundup4(ceil(K / 4))
+__host__ __device__ __forceinline__ int quarter_len(int K) { return (((K + 3) / 4) + 3) / 4 * 4; }
+
+}  // namespace qbm

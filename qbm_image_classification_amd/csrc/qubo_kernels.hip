@@ -1,0 +1,203 @@
+// qubo_kernels.hip -- HIP replacement of the QUBO annealer behind Disc_QBM.get_samples
+// (src/model/faster_dqbm.py:571-684 -> sample_sa :299-306 -> third-party dwave-neal) and of the
+// sample_Q protocol (src/qubo/sampler.py:26-33): batched heat-bath (Gibbs) sweeps on
+//     E(s) = sum_i lin_i s_i + sum_{i<j} J_ij s_i s_j,   P(s) ~ exp(-beta E).
+// The quadratic part J of Disc_QBM's QUBO is image-independent (faster_dqbm.py:242-243, 256-271);
+// only the linear field depends on the image (:239, :279), so one J[n,n] serves a whole minibatch.
+#include "qbm_device.cuh"
+#include "qbm_host.hpp"
+
+using namespace qbm;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// One wavefront per chain (image b, read r).  Lane l keeps the local fields F_i and thresholds of
+// spins i = 64 t + l (t < NF) in registers; spin bits live in wave-uniform 64-bit masks.
+// Per spin: two v_readlane (field, threshold), one multiply, one compare; on a flip every lane
+// adds +-J[i, own spins] (one coalesced row read) -- the flip decision is wave-uniform, so there is
+// no divergence.  Uniforms come from Philox (row = chain id, col = spin), one draw id per sweep.
+// ---------------------------------------------------------------------------------------------
+template <int NF>
+__global__ __launch_bounds__(256) void k_qubo_gibbs(const float* __restrict__ lin, const float* __restrict__ J,
+                                                    int nchains, int R, int n, int sweeps, float beta0,
+                                                    float beta1, uint64_t seed, uint64_t offset,
+                                                    uint8_t* __restrict__ states)
+{
+    const int lane = threadIdx.x & 63;
+    const int ch = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (ch >= nchains) return;
+    const int b = ch / R;
+    float F[NF], thr[NF];
+    unsigned long long mask[NF];
+
+    // start state s_i = (u < 0.5), draw id `offset`
+#pragma unroll
+    for (int t = 0; t < NF; ++t) {
+        const int i = 64 * t + lane;
+        bool s = false;
+        F[t] = 0.f;
+        if (i < n) {
+            const f32x4 u = uniform4(seed, offset, (uint32_t)ch, (uint32_t)(i >> 2));
+            s = u[i & 3] < 0.5f;
+            F[t] = lin[(long)b * n + i];
+        }
+        mask[t] = __ballot(s);
+    }
+    // initial fields: + J[j, :] for set spins j ascending
+#pragma unroll
+    for (int t = 0; t < NF; ++t) {
+        unsigned long long m = mask[t];
+        while (m) {
+            const int j = 64 * t + __builtin_ctzll(m);
+            m &= m - 1;
+            const float* Jr = J + (long)j * n;
+#pragma unroll
+            for (int tt = 0; tt < NF; ++tt) {
+                const int i = 64 * tt + lane;
+                if (i < n) F[tt] = F[tt] + Jr[i];
+            }
+        }
+    }
+
+    const float lr = (sweeps > 1) ? det_logf(beta1 / beta0) : 0.f;  // geometric schedule exponent
+    for (int sw = 1; sw <= sweeps; ++sw) {
+        float beta = beta1;
+        if (sweeps > 1) beta = beta0 * det_expf(lr * ((float)(sw - 1) / (float)(sweeps - 1)));
+#pragma unroll
+        for (int t = 0; t < NF; ++t) {
+            const int i = 64 * t + lane;
+            thr[t] = 0.f;
+            if (i < n) {
+                const f32x4 u4 = uniform4(seed, offset + (uint64_t)sw, (uint32_t)ch, (uint32_t)(i >> 2));
+                const float u = u4[i & 3];
+                thr[t] = -(det_logf(u) - det_logf(1.0f - u));
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NF; ++t) {
+            const int cnt = min(64, n - 64 * t);
+            for (int l = 0; l < cnt; ++l) {
+                const float Fi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, F[t]), l));
+                const float th = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, thr[t]), l));
+                const bool ns = (beta * Fi) < th;
+                const bool cur = (mask[t] >> l) & 1ull;
+                if (ns != cur) {
+                    const float sg = ns ? 1.0f : -1.0f;
+                    const float* Jr = J + (long)(64 * t + l) * n;
+#pragma unroll
+                    for (int tt = 0; tt < NF; ++tt) {
+                        const int i = 64 * tt + lane;
+                        if (i < n) F[tt] = __builtin_fmaf(sg, Jr[i], F[tt]);
+                    }
+                    mask[t] ^= (1ull << l);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NF; ++t) {
+        const int i = 64 * t + lane;
+        if (i < n) states[(long)ch * n + i] = (uint8_t)((mask[t] >> lane) & 1ull);
+    }
+}
+
+// mean over reads: sequential fp32 sum over r, divided by R
+// (np.average(np_samples, axis=0), src/model/faster_dqbm.py:780)
+__global__ __launch_bounds__(256) void k_read_mean(const uint8_t* __restrict__ states, float* __restrict__ mean,
+                                                   int B, int R, int n)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * n) return;
+    const int b = idx / n, i = idx % n;
+    float a = 0.f;
+    for (int r = 0; r < R; ++r) a = a + (float)states[((long)b * R + r) * n + i];
+    mean[idx] = a / (float)R;
+}
+
+// x-dependent part of create_qubo_matrix_from (src/model/faster_dqbm.py:236-245, 273-283): float64,
+// sequential over k, one thread per (image, variable); rounded to fp32 for the sampler.
+__global__ __launch_bounds__(256) void k_linear_fields(const double* __restrict__ X, const int* __restrict__ labels,
+                                                       const double* __restrict__ W_vh, const double* __restrict__ W_vo,
+                                                       const double* __restrict__ b_h, double b_o, int B, int D, int H,
+                                                       double beta_eff, float* __restrict__ lin)
+{
+    const int n = labels ? H : H + 1;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * n) return;
+    const int i = idx / n, v = idx % n;
+    const double* x = X + (long)i * D;
+    double a = 0.0;
+    if (!labels && v == 0) {
+        for (int k = 0; k < D; ++k) a += x[k] * W_vo[k];
+        lin[idx] = (float)((b_o + a) / beta_eff);
+        return;
+    }
+    const int j = labels ? v : v - 1;
+    if (labels) a += (double)labels[i] * W_vh[j];
+    for (int k = 0; k < D; ++k) a += x[k] * W_vh[(long)(1 + k) * H + j];
+    lin[idx] = (float)((b_h[j] + a) / beta_eff);
+}
+
+template <int NF>
+int launch_gibbs(const float* lin, const float* J, int B, int R, int n, int sweeps, float beta0, float beta1,
+                 uint64_t seed, uint64_t offset, uint8_t* states, hipStream_t st)
+{
+    const int nch = B * R;
+    hipLaunchKernelGGL((k_qubo_gibbs<NF>), dim3((nch + 3) / 4), dim3(256), 0, st, lin, J, nch, R, n, sweeps, beta0,
+                       beta1, seed, offset, states);
+    QBM_CHECK_LAUNCH("k_qubo_gibbs");
+    return QBM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qbm_qubo_gibbs(const float* lin, const float* J, int B, int R, int n, int sweeps, float beta0, float beta1,
+                   uint64_t seed, uint64_t offset, uint8_t* states, float* mean, void* stream)
+{
+    if (B < 0 || R < 0) return fail(QBM_ERR_ARG, "qubo_gibbs: negative batch/reads");
+    if (B == 0 || R == 0) return QBM_OK;
+    if (n <= 0 || n > QBM_MAX_QUBO_VARS) return fail(QBM_ERR_ARG, "qubo_gibbs: n out of range (1..QBM_MAX_QUBO_VARS)");
+    if (sweeps < 0) return fail(QBM_ERR_ARG, "qubo_gibbs: sweeps < 0");
+    if (!(beta0 > 0.f) || !(beta1 > 0.f)) return fail(QBM_ERR_ARG, "qubo_gibbs: beta must be positive");
+    if (!lin || !J || !states) return fail(QBM_ERR_ARG, "qubo_gibbs: null buffer");
+    hipStream_t st = (hipStream_t)stream;
+    const int NF = (n + 63) / 64;
+    int rc;
+    switch (NF) {
+    case 1: rc = launch_gibbs<1>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, states, st); break;
+    case 2: rc = launch_gibbs<2>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, states, st); break;
+    case 3: rc = launch_gibbs<3>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, states, st); break;
+    case 4: rc = launch_gibbs<4>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, states, st); break;
+    case 5: rc = launch_gibbs<5>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, states, st); break;
+    case 6: rc = launch_gibbs<6>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, states, st); break;
+    case 7: case 8: rc = launch_gibbs<8>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, states, st); break;
+    default: rc = launch_gibbs<16>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, states, st); break;
+    }
+    if (rc) return rc;
+    if (mean) {
+        hipLaunchKernelGGL(k_read_mean, dim3((B * n + 255) / 256), dim3(256), 0, st, states, mean, B, R, n);
+        QBM_CHECK_LAUNCH("k_read_mean");
+    }
+    return QBM_OK;
+}
+
+int qbm_qbm_linear_fields(const double* X, const int32_t* labels, const double* W_vh, const double* W_vo,
+                          const double* b_h, double b_o, int B, int D, int H, double beta_eff, float* lin,
+                          void* stream)
+{
+    if (B < 0) return fail(QBM_ERR_ARG, "linear_fields: B < 0");
+    if (B == 0) return QBM_OK;
+    if (D <= 0 || H <= 0) return fail(QBM_ERR_ARG, "linear_fields: non-positive dims");
+    if (!X || !W_vh || !W_vo || !b_h || !lin) return fail(QBM_ERR_ARG, "linear_fields: null buffer");
+    if (beta_eff == 0.0) return fail(QBM_ERR_ARG, "linear_fields: beta_eff == 0");
+    const int n = labels ? H : H + 1;
+    hipLaunchKernelGGL(k_linear_fields, dim3((B * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, X, labels, W_vh,
+                       W_vo, b_h, b_o, B, D, H, beta_eff, lin);
+    QBM_CHECK_LAUNCH("k_linear_fields");
+    return QBM_OK;
+}
+
+}  // extern "C"

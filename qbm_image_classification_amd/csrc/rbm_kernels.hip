@@ -1,0 +1,689 @@
+// rbm_kernels.hip -- ClassificationRBM hot path on gfx950 (MI355X): block-Gibbs conditionals,
+// free-energy evaluation, two-phase (CD-k / discriminative) gradient, parameter update.
+// Reference semantics: src/ClassificationRBM.py (file:line cited per kernel), SURVEY.md 8.A.
+#include "strip_mma.cuh"
+#include "qbm_host.hpp"
+
+using namespace qbm;
+
+namespace qbm {
+static thread_local char g_err[256] = "";
+
+int fail(int code, const char* msg)
+{
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* where)
+{
+    snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+    return QBM_ERR_HIP;
+}
+}  // namespace qbm
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// A-1  sample_hidden  (src/ClassificationRBM.py:43-47):  p = sigma(v.W + d + y.U);  h = (p > u)
+// MODE 0: probabilities (+ optional sample);  MODE 1: pre-activation v.W + d only (:65, :106).
+// ---------------------------------------------------------------------------------------------
+struct HiddenArgs {
+    const float* v;  // [B,V]
+    const float* y;  // [B,C] or null
+    const float* W;  // [V,H]
+    const float* d;  // [H]
+    const float* U;  // [C,H]
+    float* p;        // [B,H] or null
+    float* s;        // [B,H] or null
+    int B, V, H, C;
+    int KP;
+    uint64_t seed, offset;
+    uint32_t row0;
+    bool vecA, vecB, vecO;
+};
+
+template <int NT, int MODE>
+__global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int nM = (a.B + 15) / 16, nN = (a.H + 16 * NT - 1) / (16 * NT);
+    int ms, ns;
+    strip_coords(nM, nN, ms, ns);
+    const int m0 = ms * 16, n0 = ns * 16 * NT;
+    const ViewKContig A{a.v, a.V, a.B, a.vecA};
+    const ViewCContig Bv{a.W, a.H, a.H, a.vecB};
+    const StripOut o = strip_mma<NT, true, false>(A, Bv, m0, n0, a.V, lds, a.KP);
+    if (!o.valid) return;
+    const int i = m0 + o.row, j0 = n0 + 4 * o.cg;
+    if (i >= a.B || j0 >= a.H) return;
+    const float sv[4] = {o.sum.x, o.sum.y, o.sum.z, o.sum.w};
+    float pv[4], hv[4];
+    f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (MODE == 0 && a.s) u = uniform4(a.seed, a.offset, a.row0 + (uint32_t)i, (uint32_t)(j0 >> 2));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int j = j0 + e;
+        pv[e] = 0.f; hv[e] = 0.f;
+        if (j < a.H) {
+            float x = sv[e] + a.d[j];
+            if (MODE == 0) {
+                if (a.y) {
+                    float cls = 0.f;
+                    for (int c = 0; c < a.C; ++c)
+                        cls = __builtin_fmaf(a.y[(long)i * a.C + c], a.U[(long)c * a.H + j], cls);
+                    x = x + cls;
+                }
+                pv[e] = det_sigmoid(x);
+                hv[e] = (pv[e] > u[e]) ? 1.f : 0.f;
+            } else {
+                pv[e] = x;
+            }
+        }
+    }
+    const long off = (long)i * a.H + j0;
+    if (a.vecO && j0 + 3 < a.H) {
+        if (a.p) *reinterpret_cast<float4*>(a.p + off) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+        if (MODE == 0 && a.s) *reinterpret_cast<float4*>(a.s + off) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+    } else {
+        for (int e = 0; e < 4 && j0 + e < a.H; ++e) {
+            if (a.p) a.p[off + e] = pv[e];
+            if (MODE == 0 && a.s) a.s[off + e] = hv[e];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// A-2  sample_visible  (src/ClassificationRBM.py:49-52):  p = sigma(h.W^T + b);  v = (p > u)
+// W is read as stored ([V,H], H contiguous): it is the K-contiguous B operand.
+// ---------------------------------------------------------------------------------------------
+struct VisibleArgs {
+    const float* h;  // [B,H]
+    const float* W;  // [V,H]
+    const float* b;  // [V]
+    float* p;        // [B,V] or null
+    float* s;        // [B,V] or null
+    int B, V, H;
+    int KP;
+    uint64_t seed, offset;
+    uint32_t row0;
+    bool vecA, vecB, vecO;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_visible(VisibleArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int nM = (a.B + 15) / 16, nN = (a.V + 16 * NT - 1) / (16 * NT);
+    int ms, ns;
+    strip_coords(nM, nN, ms, ns);
+    const int m0 = ms * 16, n0 = ns * 16 * NT;
+    const ViewKContig A{a.h, a.H, a.B, a.vecA};
+    const ViewKContig Bv{a.W, a.H, a.V, a.vecB};
+    const StripOut o = strip_mma<NT, true, true>(A, Bv, m0, n0, a.H, lds, a.KP);
+    if (!o.valid) return;
+    const int i = m0 + o.row, k0 = n0 + 4 * o.cg;
+    if (i >= a.B || k0 >= a.V) return;
+    const float sv[4] = {o.sum.x, o.sum.y, o.sum.z, o.sum.w};
+    float pv[4], vv[4];
+    f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.s) u = uniform4(a.seed, a.offset, a.row0 + (uint32_t)i, (uint32_t)(k0 >> 2));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        pv[e] = 0.f; vv[e] = 0.f;
+        if (k0 + e < a.V) {
+            pv[e] = det_sigmoid(sv[e] + a.b[k0 + e]);
+            vv[e] = (pv[e] > u[e]) ? 1.f : 0.f;
+        }
+    }
+    const long off = (long)i * a.V + k0;
+    if (a.vecO && k0 + 3 < a.V) {
+        if (a.p) *reinterpret_cast<float4*>(a.p + off) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+        if (a.s) *reinterpret_cast<float4*>(a.s + off) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    } else {
+        for (int e = 0; e < 4 && k0 + e < a.V; ++e) {
+            if (a.p) a.p[off + e] = pv[e];
+            if (a.s) a.s[off + e] = vv[e];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// A-3  sample_class  (src/ClassificationRBM.py:54-60): exp(h.U^T + c), L1-normalised (eps 1e-12);
+// categorical draw: one uniform per row, first class whose running sum exceeds u.
+// One wavefront per row; the sum over j is the wave tree [T].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_class(const float* __restrict__ h, const float* __restrict__ U,
+                                               const float* __restrict__ cb, float* __restrict__ p_out,
+                                               float* __restrict__ y_out, int B, int H, int C, uint64_t seed,
+                                               uint64_t offset, uint32_t row0)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= B) return;
+    float e[QBM_MAX_CLASSES];
+    for (int c = 0; c < C; ++c) {
+        float a = 0.f;
+        for (int j = lane; j < H; j += kWave) a = __builtin_fmaf(h[(long)i * H + j], U[(long)c * H + j], a);
+        e[c] = det_expf(wave_butterfly_sum(a) + cb[c]);
+    }
+    if (lane != 0) return;
+    float denom = 0.f;
+    for (int c = 0; c < C; ++c) denom = denom + __builtin_fabsf(e[c]);
+    if (!(denom > 1e-12f)) denom = 1e-12f;
+    const float u = uniform4(seed, offset, row0 + (uint32_t)i, 0u)[0];
+    float cum = 0.f;
+    int pick = C - 1;
+    bool done = false;
+    for (int c = 0; c < C; ++c) {
+        const float p = e[c] / denom;
+        if (p_out) p_out[(long)i * C + c] = p;
+        cum = cum + p;
+        if (!done && u < cum) { pick = c; done = true; }
+    }
+    if (y_out)
+        for (int c = 0; c < C; ++c) y_out[(long)i * C + c] = (c == pick) ? 1.f : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// A-4  sample_class_given_x, second half (src/ClassificationRBM.py:68-82), given pre = x.W + d:
+//   -F_y = c_y + sum_j log(1 + exp(pre_j + U_yj));   p_c = 1 / sum_d exp(-(-F_c) + (-F_d))
+// One wavefront per row, wave tree [T] over j.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_free_energy(const float* __restrict__ pre, const float* __restrict__ U,
+                                                     const float* __restrict__ cb, float* __restrict__ negF,
+                                                     float* __restrict__ p_out, int B, int H, int C)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= B) return;
+    float nf[QBM_MAX_CLASSES];
+    for (int c = 0; c < C; ++c) {
+        float a = 0.f;
+        for (int j = lane; j < H; j += kWave) a = a + det_softplus(pre[(long)i * H + j] + U[(long)c * H + j]);
+        nf[c] = cb[c] + wave_butterfly_sum(a);
+    }
+    if (lane != 0) return;
+    for (int c = 0; c < C; ++c) {
+        if (negF) negF[(long)i * C + c] = nf[c];
+        float s = 0.f;
+        for (int dd = 0; dd < C; ++dd) s = s + det_expf((-1.0f * nf[c]) + nf[dd]);
+        if (p_out) p_out[(long)i * C + c] = 1.0f / s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// A-5  discriminative_training, elementwise stage (src/ClassificationRBM.py:106-107, :113-115,
+// :124-126):  o_c = sigma(pre + U_c);  pos = o_{label};  neg = sum_c o_c * p_c (mul, then add).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_disc_terms(const float* __restrict__ pre, const float* __restrict__ U,
+                                                    const float* __restrict__ p, const int* __restrict__ labels,
+                                                    float* __restrict__ pos, float* __restrict__ neg,
+                                                    float* __restrict__ onehot, int B, int H, int C)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * H) return;
+    const int i = (int)(idx / H), j = (int)(idx % H);
+    const float pr = pre[idx];
+    const int lab = labels[i];
+    if (j == 0 && onehot)
+        for (int c = 0; c < C; ++c) onehot[(long)i * C + c] = (c == lab) ? 1.f : 0.f;
+    float ng = 0.f, ps = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float o = det_sigmoid(pr + U[(long)c * H + j]);
+        if (c == lab) ps = o;
+        ng = ng + o * p[(long)i * C + c];
+    }
+    pos[idx] = ps;
+    neg[idx] = ng;
+}
+
+// A-5, class-weight / class-bias part (:113-115, :125, :132, :136):
+//   gU[c,j] = (onehot^T.pos)[c,j] - sum_i o_icj p_ic      (first term already in gU, from k_grad)
+//   gc[c]   = sum_i onehot_ic - sum_i p_ic
+// Batch sums are quartered chains [Q].  One thread per (c, j); thread (c, 0) also does gc[c].
+__global__ __launch_bounds__(256) void k_disc_class_grad(const float* __restrict__ pre, const float* __restrict__ U,
+                                                         const float* __restrict__ p, const int* __restrict__ labels,
+                                                         float* __restrict__ gU, float* __restrict__ gc, int B, int H,
+                                                         int C)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= C * H) return;
+    const int c = idx / H, j = idx % H;
+    const int Kq = quarter_len(B);
+    const float u = U[idx];
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < 4; ++q) {
+        const int i1 = min(B, (q + 1) * Kq);
+        float a = 0.f;
+        for (int i = q * Kq; i < i1; ++i) a = __builtin_fmaf(1.0f, det_sigmoid(pre[(long)i * H + j] + u) * p[(long)i * C + c], a);
+        part[q] = a;
+    }
+    gU[idx] = gU[idx] - (((part[0] + part[1]) + part[2]) + part[3]);
+    if (j == 0 && gc) {
+        float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 4; ++q) {
+            const int i1 = min(B, (q + 1) * Kq);
+            for (int i = q * Kq; i < i1; ++i) {
+                s0[q] = __builtin_fmaf(1.0f, (labels[i] == c) ? 1.f : 0.f, s0[q]);
+                s1[q] = __builtin_fmaf(1.0f, p[(long)i * C + c], s1[q]);
+            }
+        }
+        gc[c] = (((s0[0] + s0[1]) + s0[2]) + s0[3]) - (((s1[0] + s1[1]) + s1[2]) + s1[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// A-5 / A-7 gradient (reference association sums: src/ClassificationRBM.py:118-138):
+//   G = [A0 | Y0 | 1]^T . [P0 | 1]  -  [A1 | Y1 | 1]^T . [P1 | 1]        (contraction over the batch)
+// rows [0,V) x cols [0,H) = gW; rows [V,V+C) = gU; row V+C = gd; col H = gb (rows < V), gc (rows V..V+C).
+// Optional fused A-6 update of W (single-GPU path; the data-parallel path all-reduces G first).
+// ---------------------------------------------------------------------------------------------
+struct GradArgs {
+    const float* A0; const float* Y0; const float* P0;
+    const float* A1; const float* Y1; const float* P1;
+    float* gW; float* gb; float* gd; float* gU; float* gc;
+    float* W;  // non-null: W += ((factor*g)*lr)/bs fused (src/ClassificationRBM.py:90)
+    float lr, factor, bs;
+    int B, V, H, C;
+    int KP;
+    bool ones_col;
+    bool vecA, vecP, vecO;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_grad(GradArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int Mx = a.V + a.C + 1, Nx = a.H + (a.ones_col ? 1 : 0);
+    const int nM = (Mx + 15) / 16, nN = (Nx + 16 * NT - 1) / (16 * NT);
+    int ms, ns;
+    strip_coords(nM, nN, ms, ns);
+    const int m0 = ms * 16, n0 = ns * 16 * NT;
+    StripOut o0, o1;
+    {
+        const ViewAugData A{a.A0, a.Y0, a.V, a.C, a.vecA};
+        const ViewAugProb Bv{a.P0, a.H, a.ones_col, a.vecP};
+        o0 = strip_mma<NT, false, false>(A, Bv, m0, n0, a.B, lds, a.KP);
+    }
+    {
+        const ViewAugData A{a.A1, a.Y1, a.V, a.C, a.vecA};
+        const ViewAugProb Bv{a.P1, a.H, a.ones_col, a.vecP};
+        o1 = strip_mma<NT, false, false>(A, Bv, m0, n0, a.B, lds, a.KP);
+    }
+    if (!o0.valid) return;
+    const int m = m0 + o0.row, nb = n0 + 4 * o0.cg;
+    if (m >= Mx || nb >= Nx) return;
+    const float g[4] = {o0.sum.x - o1.sum.x, o0.sum.y - o1.sum.y, o0.sum.z - o1.sum.z, o0.sum.w - o1.sum.w};
+    if (m < a.V && nb + 3 < a.H && a.vecO) {
+        const long off = (long)m * a.H + nb;
+        if (a.gW) *reinterpret_cast<float4*>(a.gW + off) = make_float4(g[0], g[1], g[2], g[3]);
+        if (a.W) {
+            float4 w = *reinterpret_cast<const float4*>(a.W + off);
+            w.x = w.x + ((a.factor * g[0]) * a.lr) / a.bs;
+            w.y = w.y + ((a.factor * g[1]) * a.lr) / a.bs;
+            w.z = w.z + ((a.factor * g[2]) * a.lr) / a.bs;
+            w.w = w.w + ((a.factor * g[3]) * a.lr) / a.bs;
+            *reinterpret_cast<float4*>(a.W + off) = w;
+        }
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int n = nb + e;
+        if (n >= Nx) break;
+        if (n < a.H) {
+            if (m < a.V) {
+                const long off = (long)m * a.H + n;
+                if (a.gW) a.gW[off] = g[e];
+                if (a.W) a.W[off] = a.W[off] + ((a.factor * g[e]) * a.lr) / a.bs;
+            } else if (m < a.V + a.C) {
+                if (a.gU) a.gU[(long)(m - a.V) * a.H + n] = g[e];
+            } else if (a.gd) {
+                a.gd[n] = g[e];
+            }
+        } else {  // n == H: column sums of the A operand
+            if (m < a.V) { if (a.gb) a.gb[m] = g[e]; }
+            else if (m < a.V + a.C) { if (a.gc) a.gc[m - a.V] = g[e]; }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// A-6  update_weights (src/ClassificationRBM.py:88-99): theta += factor*grad*lr/batch_size, evaluated
+// left to right; then b, d, c -= sparse_constant.  One launch over the concatenated parameter blocks.
+// ---------------------------------------------------------------------------------------------
+struct UpdateArgs {
+    float* W; float* b; float* d; float* U; float* c;
+    const float* gW; const float* gb; const float* gd; const float* gU; const float* gc;
+    int V, H, C;
+    float lr, factor, bs, sparse;
+};
+
+__global__ __launch_bounds__(256) void k_update(UpdateArgs a)
+{
+    const long nW = (long)a.V * a.H, nU = (long)a.C * a.H;
+    const long total = nW + a.V + a.H + nU + a.C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float* th; const float* g; long k = i; bool sp = false;
+        if (k < nW) { th = a.W; g = a.gW; }
+        else if ((k -= nW) < a.V) { th = a.b; g = a.gb; sp = true; }
+        else if ((k -= a.V) < a.H) { th = a.d; g = a.gd; sp = true; }
+        else if ((k -= a.H) < nU) { th = a.U; g = a.gU; }
+        else { k -= nU; th = a.c; g = a.gc; sp = true; }
+        if (th == a.W && !a.gW) continue;  // W already updated by the fused gradient epilogue
+        const float gi = g ? g[k] : 0.f;   // reference: visible_bias_grad = 0 (:138)
+        float t = a.factor * gi;
+        t = t * a.lr;
+        t = t / a.bs;
+        float v = th[k] + t;
+        if (sp) v = v - a.sparse;
+        th[k] = v;
+    }
+}
+
+// test hook: det_* functions, bit-compared with the oracle
+__global__ void k_math(int which, const float* __restrict__ x, float* __restrict__ y, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    y[i] = which == 0 ? det_expf(v) : which == 1 ? det_logf(v) : which == 2 ? det_sigmoid(v) : det_softplus(v);
+}
+
+__global__ void k_uniform(uint64_t seed, uint64_t offset, uint32_t row0, int rows, int cols, float* __restrict__ out)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cgs = (cols + 3) / 4;
+    if (idx >= (long)rows * cgs) return;
+    const int i = (int)(idx / cgs), cg = (int)(idx % cgs);
+    const f32x4 u = uniform4(seed, offset, row0 + (uint32_t)i, (uint32_t)cg);
+    for (int e = 0; e < 4 && 4 * cg + e < cols; ++e) out[(long)i * cols + 4 * cg + e] = u[e];
+}
+
+// ---- launch helpers ---------------------------------------------------------------------------
+template <int NT>
+int panel_for(int K)
+{
+    const int Kq = quarter_len(K);
+    int KP = (Kq + 15) / 16 * 16;
+    const int mx = strip_max_panel<NT>();
+    return KP < mx ? KP : mx;
+}
+
+template <class Kern>
+int set_lds(Kern k, size_t bytes)
+{
+    if (bytes > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)bytes);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+    }
+    return QBM_OK;
+}
+
+int check_params(const qbm_rbm_params* P)
+{
+    if (!P) return fail(QBM_ERR_ARG, "params is null");
+    if (P->V <= 0 || P->H <= 0 || P->C <= 0) return fail(QBM_ERR_ARG, "V, H, C must be positive");
+    if (P->C > QBM_MAX_CLASSES) return fail(QBM_ERR_ARG, "C exceeds QBM_MAX_CLASSES");
+    if (!P->W || !P->b || !P->d || !P->U || !P->c) return fail(QBM_ERR_ARG, "null parameter block");
+    return QBM_OK;
+}
+
+int launch_hidden(const qbm_rbm_params* P, const float* v, const float* y, int B, float* p, float* s, int mode,
+                  uint64_t seed, uint64_t offset, uint32_t row0, hipStream_t st)
+{
+    constexpr int NT = 2;
+    HiddenArgs a{v, y, P->W, P->d, P->U, p, s, B, P->V, P->H, P->C, panel_for<NT>(P->V), seed, offset, row0,
+                 (P->V % 4 == 0) && aligned16(v), (P->H % 4 == 0) && aligned16(P->W),
+                 (P->H % 4 == 0) && (!p || aligned16(p)) && (!s || aligned16(s))};
+    const int nM = (B + 15) / 16, nN = (P->H + 16 * NT - 1) / (16 * NT);
+    const size_t lds = sizeof(float) * strip_lds_floats<NT>(a.KP);
+    if (mode == 0) {
+        if (int rc = set_lds(k_hidden<NT, 0>, lds)) return rc;
+        hipLaunchKernelGGL((k_hidden<NT, 0>), dim3(nM * nN), dim3(256), lds, st, a);
+    } else {
+        if (int rc = set_lds(k_hidden<NT, 1>, lds)) return rc;
+        hipLaunchKernelGGL((k_hidden<NT, 1>), dim3(nM * nN), dim3(256), lds, st, a);
+    }
+    QBM_CHECK_LAUNCH("k_hidden");
+    return QBM_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI (include/qbm_hip.h)
+// =================================================================================================
+extern "C" {
+
+int qbm_abi_version(void) { return QBM_ABI_VERSION; }
+const char* qbm_last_error(void) { return g_err; }
+
+int qbm_rbm_sample_hidden(const qbm_rbm_params* P, const float* v, const float* y1hot, int B, float* p_h,
+                          float* h_sample, uint64_t seed, uint64_t offset, uint32_t row0, void* stream)
+{
+    if (int rc = check_params(P)) return rc;
+    if (B < 0) return fail(QBM_ERR_ARG, "B < 0");
+    if (B == 0) return QBM_OK;
+    if (!v || (!p_h && !h_sample)) return fail(QBM_ERR_ARG, "sample_hidden: null input/output");
+    return launch_hidden(P, v, y1hot, B, p_h, h_sample, 0, seed, offset, row0, (hipStream_t)stream);
+}
+
+int qbm_rbm_hidden_preact(const qbm_rbm_params* P, const float* x, int B, float* pre, void* stream)
+{
+    if (int rc = check_params(P)) return rc;
+    if (B < 0) return fail(QBM_ERR_ARG, "B < 0");
+    if (B == 0) return QBM_OK;
+    if (!x || !pre) return fail(QBM_ERR_ARG, "hidden_preact: null input/output");
+    return launch_hidden(P, x, nullptr, B, pre, nullptr, 1, 0, 0, 0, (hipStream_t)stream);
+}
+
+int qbm_rbm_sample_visible(const qbm_rbm_params* P, const float* h, int B, float* p_v, float* v_sample,
+                           uint64_t seed, uint64_t offset, uint32_t row0, void* stream)
+{
+    if (int rc = check_params(P)) return rc;
+    if (B < 0) return fail(QBM_ERR_ARG, "B < 0");
+    if (B == 0) return QBM_OK;
+    if (!h || (!p_v && !v_sample)) return fail(QBM_ERR_ARG, "sample_visible: null input/output");
+    constexpr int NT = 4;
+    VisibleArgs a{h, P->W, P->b, p_v, v_sample, B, P->V, P->H, panel_for<NT>(P->H), seed, offset, row0,
+                  (P->H % 4 == 0) && aligned16(h), (P->H % 4 == 0) && aligned16(P->W),
+                  (P->V % 4 == 0) && (!p_v || aligned16(p_v)) && (!v_sample || aligned16(v_sample))};
+    const int nM = (B + 15) / 16, nN = (P->V + 16 * NT - 1) / (16 * NT);
+    const size_t lds = sizeof(float) * strip_lds_floats<NT>(a.KP);
+    if (int rc = set_lds(k_visible<NT>, lds)) return rc;
+    hipLaunchKernelGGL((k_visible<NT>), dim3(nM * nN), dim3(256), lds, (hipStream_t)stream, a);
+    QBM_CHECK_LAUNCH("k_visible");
+    return QBM_OK;
+}
+
+int qbm_rbm_sample_class(const qbm_rbm_params* P, const float* h, int B, float* p_y, float* y1hot, uint64_t seed,
+                         uint64_t offset, uint32_t row0, void* stream)
+{
+    if (int rc = check_params(P)) return rc;
+    if (B < 0) return fail(QBM_ERR_ARG, "B < 0");
+    if (B == 0) return QBM_OK;
+    if (!h || (!p_y && !y1hot)) return fail(QBM_ERR_ARG, "sample_class: null input/output");
+    hipLaunchKernelGGL(k_class, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, h, P->U, P->c, p_y, y1hot, B,
+                       P->H, P->C, seed, offset, row0);
+    QBM_CHECK_LAUNCH("k_class");
+    return QBM_OK;
+}
+
+int qbm_rbm_free_energy(const qbm_rbm_params* P, const float* x, int B, float* pre_ws, float* neg_free_energy,
+                        float* p_y_given_x, void* stream)
+{
+    if (int rc = check_params(P)) return rc;
+    if (B < 0) return fail(QBM_ERR_ARG, "B < 0");
+    if (B == 0) return QBM_OK;
+    if (!x || !pre_ws || (!neg_free_energy && !p_y_given_x)) return fail(QBM_ERR_ARG, "free_energy: null buffer");
+    if (int rc = launch_hidden(P, x, nullptr, B, pre_ws, nullptr, 1, 0, 0, 0, (hipStream_t)stream)) return rc;
+    hipLaunchKernelGGL(k_free_energy, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, pre_ws, P->U, P->c,
+                       neg_free_energy, p_y_given_x, B, P->H, P->C);
+    QBM_CHECK_LAUNCH("k_free_energy");
+    return QBM_OK;
+}
+
+int qbm_rbm_disc_terms(const qbm_rbm_params* P, const float* pre, const float* p_y, const int32_t* labels, int B,
+                       float* pos, float* neg, float* onehot, void* stream)
+{
+    if (int rc = check_params(P)) return rc;
+    if (B <= 0) return B == 0 ? QBM_OK : fail(QBM_ERR_ARG, "B < 0");
+    if (!pre || !p_y || !labels || !pos || !neg) return fail(QBM_ERR_ARG, "disc_terms: null buffer");
+    const long n = (long)B * P->H;
+    hipLaunchKernelGGL(k_disc_terms, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pre, P->U,
+                       p_y, labels, pos, neg, onehot, B, P->H, P->C);
+    QBM_CHECK_LAUNCH("k_disc_terms");
+    return QBM_OK;
+}
+
+int qbm_rbm_disc_class_grad(const qbm_rbm_params* P, const float* pre, const float* p_y, const int32_t* labels,
+                            int B, float* gU, float* gc, void* stream)
+{
+    if (int rc = check_params(P)) return rc;
+    if (B <= 0) return B == 0 ? QBM_OK : fail(QBM_ERR_ARG, "B < 0");
+    if (!pre || !p_y || !labels || !gU) return fail(QBM_ERR_ARG, "disc_class_grad: null buffer");
+    const int n = P->C * P->H;
+    hipLaunchKernelGGL(k_disc_class_grad, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pre, P->U, p_y,
+                       labels, gU, gc, B, P->H, P->C);
+    QBM_CHECK_LAUNCH("k_disc_class_grad");
+    return QBM_OK;
+}
+
+int qbm_rbm_two_phase_grad(int V, int H, int C, int B, const float* A0, const float* Y0, const float* P0,
+                           const float* A1, const float* Y1, const float* P1, const qbm_rbm_grads* G, float* W_fused,
+                           float lr, float factor, float batch_size, void* stream)
+{
+    if (V <= 0 || H <= 0 || C <= 0 || B <= 0) return fail(QBM_ERR_ARG, "two_phase_grad: non-positive dims");
+    if (!A0 || !P0 || !A1 || !P1 || !G) return fail(QBM_ERR_ARG, "two_phase_grad: null operand");
+    if (!G->gW && !W_fused) return fail(QBM_ERR_ARG, "two_phase_grad: neither gW nor fused W given");
+    constexpr int NT = 2;
+    GradArgs a{A0, Y0, P0, A1, Y1, P1, G->gW, G->gb, G->gd, G->gU, G->gc, W_fused, lr, factor, batch_size, B, V, H, C,
+               panel_for<NT>(B), (G->gb != nullptr) || (G->gc != nullptr),
+               (V % 4 == 0) && aligned16(A0) && aligned16(A1), (H % 4 == 0) && aligned16(P0) && aligned16(P1),
+               (H % 4 == 0) && (!G->gW || aligned16(G->gW)) && (!W_fused || aligned16(W_fused))};
+    const int Mx = V + C + 1, Nx = H + (a.ones_col ? 1 : 0);
+    const int nM = (Mx + 15) / 16, nN = (Nx + 16 * NT - 1) / (16 * NT);
+    const size_t lds = sizeof(float) * strip_lds_floats<NT>(a.KP);
+    if (int rc = set_lds(k_grad<NT>, lds)) return rc;
+    hipLaunchKernelGGL((k_grad<NT>), dim3(nM * nN), dim3(256), lds, (hipStream_t)stream, a);
+    QBM_CHECK_LAUNCH("k_grad");
+    return QBM_OK;
+}
+
+int qbm_rbm_update(const qbm_rbm_params* P, const qbm_rbm_grads* G, float lr, float factor, float batch_size,
+                   float sparse_constant, void* stream)
+{
+    if (int rc = check_params(P)) return rc;
+    if (!G) return fail(QBM_ERR_ARG, "update: grads is null");
+    if (!(batch_size > 0.f)) return fail(QBM_ERR_ARG, "update: batch_size must be positive");
+    UpdateArgs a{P->W, P->b, P->d, P->U, P->c, G->gW, G->gb, G->gd, G->gU, G->gc, P->V, P->H, P->C,
+                 lr, factor, batch_size, sparse_constant};
+    const long total = (long)P->V * P->H + P->V + P->H + (long)P->C * P->H + P->C;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(k_update, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    QBM_CHECK_LAUNCH("k_update");
+    return QBM_OK;
+}
+
+int qbm_rbm_cd_chain(const qbm_rbm_params* P, const float* v0, const float* y0, int B, int k, uint64_t seed,
+                     uint64_t offset, uint32_t row0, float* chain_v, float* chain_y, const qbm_rbm_cd_workspace* ws,
+                     void* stream)
+{
+    if (int rc = check_params(P)) return rc;
+    if (B <= 0) return B == 0 ? QBM_OK : fail(QBM_ERR_ARG, "B < 0");
+    if (k < 1) return fail(QBM_ERR_ARG, "cd_chain: k must be >= 1");
+    if (!v0 || !y0 || !ws || !ws->ph0 || !ws->h || !ws->vk || !ws->yk || !ws->phk)
+        return fail(QBM_ERR_ARG, "cd_chain: null buffer");
+    if ((chain_v == nullptr) != (chain_y == nullptr)) return fail(QBM_ERR_ARG, "cd_chain: chain_v and chain_y go together");
+    hipStream_t st = (hipStream_t)stream;
+    if (chain_v) {
+        // positive phase on the data (probabilities only), negative chain from the persistent state
+        if (int rc = launch_hidden(P, v0, y0, B, ws->ph0, nullptr, 0, seed, offset, row0, st)) return rc;
+        if (int rc = launch_hidden(P, chain_v, chain_y, B, nullptr, ws->h, 0, seed, offset, row0, st)) return rc;
+    } else {
+        if (int rc = launch_hidden(P, v0, y0, B, ws->ph0, ws->h, 0, seed, offset, row0, st)) return rc;
+    }
+    for (int t = 1; t <= k; ++t) {
+        const uint64_t o = offset + 3ull * (uint64_t)t;
+        if (int rc = qbm_rbm_sample_visible(P, ws->h, B, nullptr, ws->vk, seed, o - 2, row0, stream)) return rc;
+        if (int rc = qbm_rbm_sample_class(P, ws->h, B, nullptr, ws->yk, seed, o - 1, row0, stream)) return rc;
+        if (int rc = launch_hidden(P, ws->vk, ws->yk, B, ws->phk, ws->h, 0, seed, o, row0, st)) return rc;
+    }
+    if (chain_v) {
+        hipError_t e = hipMemcpyAsync(chain_v, ws->vk, sizeof(float) * (size_t)B * P->V, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(chain_v)");
+        e = hipMemcpyAsync(chain_y, ws->yk, sizeof(float) * (size_t)B * P->C, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(chain_y)");
+    }
+    return QBM_OK;
+}
+
+int qbm_rbm_cd_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const float* v0, const float* y0, int B, int k,
+                    uint64_t seed, uint64_t offset, uint32_t row0, float* chain_v, float* chain_y,
+                    const qbm_rbm_cd_workspace* ws, int fuse_update, float lr, float factor, float batch_size,
+                    float sparse_constant, void* stream)
+{
+    if (!G) return fail(QBM_ERR_ARG, "cd_step: grads is null");
+    if (!G->gb || !G->gd || !G->gU || !G->gc) return fail(QBM_ERR_ARG, "cd_step: gb, gd, gU, gc are required");
+    if (!fuse_update && !G->gW) return fail(QBM_ERR_ARG, "cd_step: gW is required without fuse_update");
+    if (int rc = qbm_rbm_cd_chain(P, v0, y0, B, k, seed, offset, row0, chain_v, chain_y, ws, stream)) return rc;
+    if (B == 0) return QBM_OK;
+    qbm_rbm_grads g = *G;
+    if (fuse_update) g.gW = nullptr;
+    if (int rc = qbm_rbm_two_phase_grad(P->V, P->H, P->C, B, v0, y0, ws->ph0, ws->vk, ws->yk, ws->phk, &g,
+                                        fuse_update ? P->W : nullptr, lr, factor, batch_size, stream))
+        return rc;
+    if (fuse_update) return qbm_rbm_update(P, &g, lr, factor, batch_size, sparse_constant, stream);
+    return QBM_OK;
+}
+
+int qbm_rbm_disc_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const float* x, const int32_t* labels, int B,
+                      float* p_y, float* neg_free_energy, const qbm_rbm_disc_workspace* ws, int apply_update,
+                      int fuse_update, float lr, float factor, float batch_size, float sparse_constant, void* stream)
+{
+    if (int rc = check_params(P)) return rc;
+    if (B <= 0) return B == 0 ? QBM_OK : fail(QBM_ERR_ARG, "B < 0");
+    if (!G || !G->gd || !G->gU || !G->gc) return fail(QBM_ERR_ARG, "disc_step: gd, gU, gc are required");
+    if (!x || !labels || !p_y || !ws || !ws->pre || !ws->pos || !ws->neg || !ws->onehot)
+        return fail(QBM_ERR_ARG, "disc_step: null buffer");
+    const bool fuse = apply_update && fuse_update;
+    if (!fuse && !G->gW) return fail(QBM_ERR_ARG, "disc_step: gW is required unless the update is fused");
+    if (int rc = qbm_rbm_free_energy(P, x, B, ws->pre, neg_free_energy, p_y, stream)) return rc;
+    if (int rc = qbm_rbm_disc_terms(P, ws->pre, p_y, labels, B, ws->pos, ws->neg, ws->onehot, stream)) return rc;
+    qbm_rbm_grads g = *G;
+    g.gb = nullptr;  // reference: visible_bias_grad = 0 (src/ClassificationRBM.py:138)
+    g.gc = nullptr;  // written by disc_class_grad below
+    if (fuse) g.gW = nullptr;
+    if (int rc = qbm_rbm_two_phase_grad(P->V, P->H, P->C, B, x, ws->onehot, ws->pos, x, nullptr, ws->neg, &g,
+                                        fuse ? P->W : nullptr, lr, factor, batch_size, stream))
+        return rc;
+    if (int rc = qbm_rbm_disc_class_grad(P, ws->pre, p_y, labels, B, G->gU, G->gc, stream)) return rc;
+    if (apply_update) {
+        g.gc = G->gc;
+        return qbm_rbm_update(P, &g, lr, factor, batch_size, sparse_constant, stream);
+    }
+    return QBM_OK;
+}
+
+int qbm_test_math(int which, const float* x, float* y, int n, void* stream)
+{
+    if (n <= 0) return QBM_OK;
+    hipLaunchKernelGGL(k_math, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, which, x, y, n);
+    QBM_CHECK_LAUNCH("k_math");
+    return QBM_OK;
+}
+
+int qbm_test_uniform(uint64_t seed, uint64_t offset, uint32_t row0, int rows, int cols, float* out, void* stream)
+{
+    if (rows <= 0 || cols <= 0) return QBM_OK;
+    const long n = (long)rows * ((cols + 3) / 4);
+    hipLaunchKernelGGL(k_uniform, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, offset,
+                       row0, rows, cols, out);
+    QBM_CHECK_LAUNCH("k_uniform");
+    return QBM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,241 @@
+// strip_mma.cuh -- the K-quartered strip contraction every dense product of the path runs on.
+//
+// One workgroup = 4 wavefronts = the 4 SIMDs of one CU.  It owns a 16 x (16*NT) strip of the
+// output.  Wave q contracts K-quarter q ([Q] of the numerical contract) with
+// v_mfma_f32_16x16x4_f32, NT independent accumulators per wave (NT >= 2 reaches the MFMA issue
+// rate: 32-cycle issue vs 40-cycle dependent latency).  The four partial strips meet in LDS and
+// are added ((q0+q1)+q2)+q3; the caller's epilogue then runs on a row-major thread map
+// (thread -> one row, 4 consecutive columns) so that one Philox4x32 call serves one thread and
+// stores are 16 B wide.
+//
+// Operand tiles go through LDS in two images chosen so that the per-lane MFMA fragment read is a
+// conflict-free, lane-linear ds_read_b32 of 64 consecutive dwords:
+//   "k4"  image (operand whose K index is contiguous in memory: activations [B, features], and W
+//         when it is applied transposed): float4 slot (k/4)*16 + r  -> fragment dword
+//         s*64 + (lane&15)*4 + (lane>>4)
+//   "lin" image (operand whose M/N index is contiguous: W[k][n], P[b][n], data[b][m] for the
+//         gradient): dword k*16 + r -> fragment dword s*64 + lane
+// Both images are filled 1 KiB per wave-instruction in lane order (slot = piece*64 + lane), i.e.
+// in the order an LDS-DMA (global_load_lds_dwordx4) writes.
+#pragma once
+#include "qbm_device.cuh"
+
+namespace qbm {
+
+// ---- operand views: get() returns 4 consecutive elements, zero outside the operand -----------
+
+// element(row, k) = p[row*ld + k]; 4 consecutive k
+struct ViewKContig {
+    const float* p;
+    long ld;
+    int rows;
+    bool vec;  // ld % 4 == 0 and p 16-byte aligned
+    __device__ __forceinline__ float4 get(int row, int k, int kend) const
+    {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < rows && k < kend) {
+            const float* q = p + (long)row * ld + k;
+            if (vec && k + 3 < kend) {
+                v = *reinterpret_cast<const float4*>(q);
+            } else {
+                v.x = q[0];
+                if (k + 1 < kend) v.y = q[1];
+                if (k + 2 < kend) v.z = q[2];
+                if (k + 3 < kend) v.w = q[3];
+            }
+        }
+        return v;
+    }
+};
+
+// element(k, c) = p[k*ld + c]; 4 consecutive c
+struct ViewCContig {
+    const float* p;
+    long ld;
+    int cols;
+    bool vec;
+    __device__ __forceinline__ float4 get(int k, int c, int kend) const
+    {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < kend && c < cols) {
+            const float* q = p + (long)k * ld + c;
+            if (vec && c + 3 < cols) {
+                v = *reinterpret_cast<const float4*>(q);
+            } else {
+                v.x = q[0];
+                if (c + 1 < cols) v.y = q[1];
+                if (c + 2 < cols) v.z = q[2];
+                if (c + 3 < cols) v.w = q[3];
+            }
+        }
+        return v;
+    }
+};
+
+// Gradient A operand, augmented: m in [0,V) -> data[k][m]; [V,V+C) -> onehot/prob Y[k][m-V] (if Y);
+// m == V+C -> 1 (column sums of the B operand).  element(k, m), 4 consecutive m.
+struct ViewAugData {
+    const float* data;  // [B, V]
+    const float* Y;     // [B, C] or nullptr
+    int V, C;
+    bool vec;
+    __device__ __forceinline__ float one(int k, int m) const
+    {
+        if (m < V) return data[(long)k * V + m];
+        if (m < V + C) return Y ? Y[(long)k * C + (m - V)] : 0.f;
+        return (m == V + C) ? 1.f : 0.f;
+    }
+    __device__ __forceinline__ float4 get(int k, int m, int kend) const
+    {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < kend) {
+            if (vec && m + 3 < V) {
+                v = *reinterpret_cast<const float4*>(data + (long)k * V + m);
+            } else {
+                v.x = one(k, m); v.y = one(k, m + 1); v.z = one(k, m + 2); v.w = one(k, m + 3);
+            }
+        }
+        return v;
+    }
+};
+
+// Gradient B operand, augmented: n in [0,H) -> P[k][n]; n == H -> 1 (column sums of the A operand).
+struct ViewAugProb {
+    const float* P;  // [B, H]
+    int H;
+    bool ones;
+    bool vec;
+    __device__ __forceinline__ float one(int k, int n) const
+    {
+        if (n < H) return P[(long)k * H + n];
+        return (ones && n == H) ? 1.f : 0.f;
+    }
+    __device__ __forceinline__ float4 get(int k, int n, int kend) const
+    {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < kend) {
+            if (vec && n + 3 < H) {
+                v = *reinterpret_cast<const float4*>(P + (long)k * H + n);
+            } else {
+                v.x = one(k, n); v.y = one(k, n + 1); v.z = one(k, n + 2); v.w = one(k, n + 3);
+            }
+        }
+        return v;
+    }
+};
+
+// LDS floats needed by one workgroup for panel length KP (multiple of 16)
+template <int NT>
+__host__ __device__ constexpr int strip_lds_floats(int KP) { return 4 * (NT + 1) * 16 * KP; }
+
+// largest panel that fits 160 KiB with 4 waves, multiple of 16
+template <int NT>
+__host__ __device__ constexpr int strip_max_panel() { return (163840 / 4 / ((NT + 1) * 64)) / 16 * 16; }
+
+struct StripOut {
+    float4 sum;  // ((q0+q1)+q2)+q3 for columns n0+4*cg .. +3 of row m0+row
+    int row;     // 0..15
+    int cg;      // 0..4*NT-1
+    bool valid;  // this thread holds an output
+};
+
+// A_K4 / B_K4: the operand's K index is the contiguous one (k4 image), else lin image.
+//   A_K4: A.get(row, k, kend)   else A.get(k, m, kend)
+//   B_K4: B.get(col, k, kend)   else B.get(k, n, kend)
+template <int NT, bool A_K4, bool B_K4, class AView, class BView>
+__device__ __forceinline__ StripOut strip_mma(const AView& A, const BView& Bv, int m0, int n0, int K,
+                                              float* __restrict__ lds, int KP)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int q = tid >> 6;  // wave id == K quarter
+    const int Kq = quarter_len(K);
+    const int kq0 = q * Kq;
+    const int kend = min(K, kq0 + Kq);
+    float* img = lds + (size_t)q * (NT + 1) * 16 * KP;
+    float4* imgA4 = reinterpret_cast<float4*>(img);
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fragA = A_K4 ? ((lane & 15) * 4 + (lane >> 4)) : lane;
+    const int fragB = B_K4 ? ((lane & 15) * 4 + (lane >> 4)) : lane;
+
+    for (int kb = kq0; kb < kq0 + Kq; kb += KP) {  // Kq is the same for all waves: uniform trip count
+        const int klen = max(0, min(kend - kb, KP));
+        const int pieces = (klen + 15) >> 4;
+        for (int pc = 0; pc < pieces; ++pc) {
+            const int slot = pc * 64 + lane;
+            float4 va;
+            if (A_K4) va = A.get(m0 + (slot & 15), kb + 4 * (slot >> 4), kend);
+            else      va = A.get(kb + (slot >> 2), m0 + 4 * (slot & 3), kend);
+            imgA4[slot] = va;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float4 vb;
+                if (B_K4) vb = Bv.get(n0 + 16 * t + (slot & 15), kb + 4 * (slot >> 4), kend);
+                else      vb = Bv.get(kb + (slot >> 2), n0 + 16 * t + 4 * (slot & 3), kend);
+                reinterpret_cast<float4*>(img + (size_t)(1 + t) * 16 * KP)[slot] = vb;
+            }
+        }
+        __syncthreads();
+        const int ksteps = (klen + 3) >> 2;
+        for (int s = 0; s < ksteps; ++s) {
+            const float a = img[s * 64 + fragA];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float b = img[(size_t)(1 + t) * 16 * KP + s * 64 + fragB];
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // partial strips -> LDS (each wave reuses the head of its own staging region), row-major
+    // [16][RS], RS = 16*NT + 4 (the +4 keeps lanes l and l+16, four rows apart, on different banks)
+    constexpr int RS = 16 * NT + 4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) img[((lane >> 4) * 4 + r) * RS + 16 * t + (lane & 15)] = acc[t][r];
+    __syncthreads();
+
+    StripOut o;
+    o.valid = tid < 64 * NT;
+    o.row = tid / (4 * NT);
+    o.cg = tid % (4 * NT);
+    o.sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (o.valid) {
+        const size_t wstride = (size_t)(NT + 1) * 16 * KP;
+        const float* base = lds + o.row * RS + 4 * o.cg;
+        const float4 p0 = *reinterpret_cast<const float4*>(base);
+        const float4 p1 = *reinterpret_cast<const float4*>(base + wstride);
+        const float4 p2 = *reinterpret_cast<const float4*>(base + 2 * wstride);
+        const float4 p3 = *reinterpret_cast<const float4*>(base + 3 * wstride);
+        o.sum.x = ((p0.x + p1.x) + p2.x) + p3.x;
+        o.sum.y = ((p0.y + p1.y) + p2.y) + p3.y;
+        o.sum.z = ((p0.z + p1.z) + p2.z) + p3.z;
+        o.sum.w = ((p0.w + p1.w) + p2.w) + p3.w;
+    }
+    __syncthreads();  // the partials are consumed: the caller may run another contraction on this LDS
+    return o;
+}
+
+// Speed-only remap of blockIdx -> (m strip, n strip): workgroups that read the same B panel
+// (same n strip) are dealt to the same XCD (blocks b and b+8 share one), so that each XCD's L2
+// holds 1/8 of the B operand.  Falls back to the plain map when nN is not a multiple of 8.
+__device__ __forceinline__ void strip_coords(int nM, int nN, int& ms, int& ns)
+{
+    const int id = blockIdx.x;
+    if ((nN & 7) == 0) {
+        const int x = id & 7, j = id >> 3;
+        ns = x + 8 * (j / nM);
+        ms = j % nM;
+    } else {
+        ms = id / nN;
+        ns = id % nN;
+    }
+}
+
+}  // namespace qbm

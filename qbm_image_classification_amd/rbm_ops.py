@@ -1,0 +1,182 @@
+"""Tensor-level front end of the RBM entry points of libqbm_hip.so (include/qbm_hip.h).
+
+Everything here is plumbing: torch ROCm tensors in, tensors out, device pointers handed to the C ABI
+on torch's current stream.  No arithmetic of the hot path happens in Python, and there is no CPU
+fallback -- a missing library or a CPU tensor raises QbmHipError."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import CdWorkspace, DiscWorkspace, RbmGrads, RbmParams, check, current_stream, ptr
+
+
+class ParamSet:
+    """The five parameter blocks of a ClassificationRBM (src/ClassificationRBM.py:26-30) on the device."""
+
+    def __init__(self, W, b, d, U, c):
+        self.W, self.b, self.d, self.U, self.c = W, b, d, U, c
+        self.V, self.H = W.shape
+        self.C = U.shape[0]
+        for t in (W, b, d, U, c):
+            if t.dtype != torch.float32:
+                raise _lib.QbmHipError("parameters must be float32")
+
+    def struct(self) -> RbmParams:
+        return RbmParams(ptr(self.W), ptr(self.b), ptr(self.d), ptr(self.U), ptr(self.c), self.V, self.H, self.C)
+
+
+class GradSet:
+    """One flat fp32 buffer [gW | gb | gd | gU | gc | n_rows] with views: the data-parallel path
+    all-reduces `flat` once per step; the last element carries the local row count."""
+
+    def __init__(self, V, H, C, device):
+        self.V, self.H, self.C = V, H, C
+        n = V * H + V + H + C * H + C
+        # 16-byte aligned blocks are not required by the ABI (it falls back to scalar accesses), the
+        # flat layout simply follows the reference's attribute order
+        self.flat = torch.zeros(n + 1, dtype=torch.float32, device=device)
+        o = 0
+        self.gW = self.flat[o:o + V * H].view(V, H); o += V * H
+        self.gb = self.flat[o:o + V]; o += V
+        self.gd = self.flat[o:o + H]; o += H
+        self.gU = self.flat[o:o + C * H].view(C, H); o += C * H
+        self.gc = self.flat[o:o + C]; o += C
+        self.count = self.flat[o:o + 1]
+
+    def struct(self, with_gW=True, with_gb=True) -> RbmGrads:
+        return RbmGrads(ptr(self.gW) if with_gW else None, ptr(self.gb) if with_gb else None, ptr(self.gd),
+                        ptr(self.gU), ptr(self.gc))
+
+
+def _f32(t, device):
+    t = torch.as_tensor(t)
+    if t.dtype != torch.float32 or t.device != device or not t.is_contiguous():
+        t = t.to(device=device, dtype=torch.float32).contiguous()
+    return t
+
+
+class HipRbmOps:
+    """The HIP backend.  (tests/ substitute an oracle-backed double with the same methods to exercise
+    the host logic on CPU; the product never does.)"""
+
+    name = "hip"
+
+    def __init__(self, device="cuda:0"):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.QbmHipError("no ROCm device visible: the HIP path cannot run (there is no CPU fallback)")
+        self.device = torch.device(device)
+
+    # ---- conditionals -------------------------------------------------------------------------
+    def sample_hidden(self, P: ParamSet, v, y=None, seed=0, offset=0, row0=0, want_p=True, want_s=False):
+        v = _f32(v, self.device)
+        y = None if y is None else _f32(y, self.device)
+        B = v.shape[0]
+        p = torch.empty(B, P.H, dtype=torch.float32, device=self.device) if want_p else None
+        s = torch.empty(B, P.H, dtype=torch.float32, device=self.device) if want_s else None
+        ps = P.struct()
+        check(self.lib.qbm_rbm_sample_hidden(C.byref(ps), ptr(v), ptr(y), B, ptr(p), ptr(s), seed, offset, row0,
+                                             current_stream()), "qbm_rbm_sample_hidden")
+        return p, s
+
+    def hidden_preact(self, P: ParamSet, x):
+        x = _f32(x, self.device)
+        pre = torch.empty(x.shape[0], P.H, dtype=torch.float32, device=self.device)
+        ps = P.struct()
+        check(self.lib.qbm_rbm_hidden_preact(C.byref(ps), ptr(x), x.shape[0], ptr(pre), current_stream()),
+              "qbm_rbm_hidden_preact")
+        return pre
+
+    def sample_visible(self, P: ParamSet, h, seed=0, offset=0, row0=0, want_p=True, want_s=False):
+        h = _f32(h, self.device)
+        B = h.shape[0]
+        p = torch.empty(B, P.V, dtype=torch.float32, device=self.device) if want_p else None
+        s = torch.empty(B, P.V, dtype=torch.float32, device=self.device) if want_s else None
+        ps = P.struct()
+        check(self.lib.qbm_rbm_sample_visible(C.byref(ps), ptr(h), B, ptr(p), ptr(s), seed, offset, row0,
+                                              current_stream()), "qbm_rbm_sample_visible")
+        return p, s
+
+    def sample_class(self, P: ParamSet, h, seed=0, offset=0, row0=0, want_p=True, want_s=False):
+        h = _f32(h, self.device)
+        B = h.shape[0]
+        p = torch.empty(B, P.C, dtype=torch.float32, device=self.device) if want_p else None
+        s = torch.empty(B, P.C, dtype=torch.float32, device=self.device) if want_s else None
+        ps = P.struct()
+        check(self.lib.qbm_rbm_sample_class(C.byref(ps), ptr(h), B, ptr(p), ptr(s), seed, offset, row0,
+                                            current_stream()), "qbm_rbm_sample_class")
+        return p, s
+
+    def free_energy(self, P: ParamSet, x):
+        """-> (-F [B,C], p(y|x) [B,C])"""
+        x = _f32(x, self.device)
+        B = x.shape[0]
+        pre = torch.empty(B, P.H, dtype=torch.float32, device=self.device)
+        nf = torch.empty(B, P.C, dtype=torch.float32, device=self.device)
+        p = torch.empty(B, P.C, dtype=torch.float32, device=self.device)
+        ps = P.struct()
+        check(self.lib.qbm_rbm_free_energy(C.byref(ps), ptr(x), B, ptr(pre), ptr(nf), ptr(p), current_stream()),
+              "qbm_rbm_free_energy")
+        return nf, p
+
+    # ---- training steps -----------------------------------------------------------------------
+    def disc_step(self, P: ParamSet, G: GradSet, x, labels, apply_update, fuse, lr, factor, batch_size, sparse):
+        """One discriminative_training pass (src/ClassificationRBM.py:101-140). -> p(y|x) [B,C]"""
+        x = _f32(x, self.device)
+        labels = torch.as_tensor(labels).to(device=self.device, dtype=torch.int32).contiguous()
+        B = x.shape[0]
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.device)
+        pre, pos, neg, oh, p = f(B, P.H), f(B, P.H), f(B, P.H), f(B, P.C), f(B, P.C)
+        ws = DiscWorkspace(ptr(pre), ptr(pos), ptr(neg), ptr(oh))
+        ps, gs = P.struct(), G.struct(with_gb=False)
+        check(self.lib.qbm_rbm_disc_step(C.byref(ps), C.byref(gs), ptr(x), ptr(labels), B, ptr(p), None, C.byref(ws),
+                                         int(apply_update), int(fuse), lr, factor, batch_size, sparse,
+                                         current_stream()), "qbm_rbm_disc_step")
+        return p
+
+    def cd_step(self, P: ParamSet, G: GradSet, v0, y0, k, seed, offset, row0, chain_v, chain_y, fuse, lr, factor,
+                batch_size, sparse, ws=None):
+        """CD-k / PCD step: chain + gradient (+ fused update when `fuse`)."""
+        v0, y0 = _f32(v0, self.device), _f32(y0, self.device)
+        B = v0.shape[0]
+        if ws is None:
+            ws = self.cd_workspace(P, B)
+        cws = CdWorkspace(*(ptr(t) for t in ws))
+        ps, gs = P.struct(), G.struct()
+        check(self.lib.qbm_rbm_cd_step(C.byref(ps), C.byref(gs), ptr(v0), ptr(y0), B, k, seed, offset, row0,
+                                       ptr(chain_v), ptr(chain_y), C.byref(cws), int(fuse), lr, factor, batch_size,
+                                       sparse, current_stream()), "qbm_rbm_cd_step")
+        return ws
+
+    def cd_workspace(self, P: ParamSet, B):
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.device)
+        return (f(B, P.H), f(B, P.H), f(B, P.V), f(B, P.C), f(B, P.H))  # ph0, h, vk, yk, phk
+
+    def update(self, P: ParamSet, G: GradSet, lr, factor, batch_size, sparse, with_gb=True):
+        ps, gs = P.struct(), G.struct(with_gb=with_gb)
+        check(self.lib.qbm_rbm_update(C.byref(ps), C.byref(gs), lr, factor, batch_size, sparse, current_stream()),
+              "qbm_rbm_update")
+
+    def two_phase_grad(self, V, H, Cn, A0, Y0, P0, A1, Y1, P1, G: GradSet):
+        B = A0.shape[0]
+        gs = G.struct()
+        check(self.lib.qbm_rbm_two_phase_grad(V, H, Cn, B, ptr(A0), ptr(Y0), ptr(P0), ptr(A1), ptr(Y1), ptr(P1),
+                                              C.byref(gs), None, 0.0, 0.0, 1.0, current_stream()),
+              "qbm_rbm_two_phase_grad")
+
+    # ---- test hooks ---------------------------------------------------------------------------
+    def math(self, which, x):
+        x = _f32(x, self.device)
+        y = torch.empty_like(x)
+        check(self.lib.qbm_test_math({"exp": 0, "log": 1, "sigmoid": 2, "softplus": 3}[which], ptr(x), ptr(y),
+                                     x.numel(), current_stream()), "qbm_test_math")
+        return y
+
+    def uniform(self, seed, offset, row0, rows, cols):
+        out = torch.empty(rows, cols, dtype=torch.float32, device=self.device)
+        check(self.lib.qbm_test_uniform(seed, offset, row0, rows, cols, ptr(out), current_stream()),
+              "qbm_test_uniform")
+        return out

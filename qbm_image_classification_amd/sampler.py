@@ -1,0 +1,85 @@
+"""HIP Gibbs sampler behind the reference's two sampler boundaries:
+
+  B2  `sample_Q(Q, num_reads) -> float32[num_reads, n]` -- the protocol of src/qubo/sampler.py:26-33
+      (LocalSASampler / DWaveAdapter), consumed by src/train/pipeline.py:20,35;
+  B3  the sampler dispatch of Disc_QBM.get_samples (src/model/faster_dqbm.py:571-684), used through
+      HipQuboOps by disc_qbm.Disc_QBM(solver="HIP").
+
+The annealer the reference calls (dwave-neal 0.5.9, absent here) is replaced by heat-bath sweeps on the
+GPU (csrc/qubo_kernels.hip).  No CPU fallback: a missing library or GPU raises QbmHipError."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, current_stream, ptr
+
+
+class HipQuboOps:
+    def __init__(self, device="cuda:0"):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.QbmHipError("no ROCm device visible: the HIP path cannot run (there is no CPU fallback)")
+        self.device = torch.device(device)
+
+    def gibbs(self, lin, J, reads, sweeps, beta0=1.0, beta1=1.0, seed=0, offset=0, want_mean=True):
+        """lin [B,n] f32, J [n,n] f32 symmetric zero-diagonal (device tensors) -> (states u8 [B,R,n], mean [B,n])"""
+        lin = lin.to(self.device, torch.float32).contiguous()
+        J = J.to(self.device, torch.float32).contiguous()
+        B, n = lin.shape
+        if J.shape != (n, n):
+            raise _lib.QbmHipError(f"J must be [{n},{n}], got {tuple(J.shape)}")
+        states = torch.empty(B, reads, n, dtype=torch.uint8, device=self.device)
+        mean = torch.empty(B, n, dtype=torch.float32, device=self.device) if want_mean else None
+        check(self.lib.qbm_qubo_gibbs(ptr(lin), ptr(J), B, reads, n, sweeps, beta0, beta1, seed, offset, ptr(states),
+                                      ptr(mean), current_stream()), "qbm_qubo_gibbs")
+        return states, mean
+
+    def linear_fields(self, X, labels, W_vh, W_vo, b_h, b_o, beta_eff=1.0):
+        """x-dependent QUBO diagonal of Disc_QBM.create_qubo_matrix_from (faster_dqbm.py:225-284), f64 in,
+        fp32 [B,n] out on the device.  labels None = unclamped (n = 1+H), else clamped (n = H)."""
+        d64 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(self.device) \
+            if not torch.is_tensor(a) else a.to(self.device, torch.float64).contiguous()
+        X, W_vh, b_h = d64(X), d64(W_vh), d64(b_h)
+        W_vo = d64(W_vo).reshape(-1)
+        B, D = X.shape
+        H = W_vh.shape[1]
+        if W_vh.shape[0] != D + 1:
+            raise _lib.QbmHipError("W_vh must have 1 + dim_input rows (row 0 = label row)")
+        lab = None if labels is None else torch.as_tensor(np.asarray(labels)).to(self.device, torch.int32).contiguous()
+        n = H if lab is not None else H + 1
+        lin = torch.empty(B, n, dtype=torch.float32, device=self.device)
+        b_o = float(np.asarray(b_o.cpu() if torch.is_tensor(b_o) else b_o).reshape(-1)[0])
+        check(self.lib.qbm_qbm_linear_fields(ptr(X), ptr(lab), ptr(W_vh), ptr(W_vo), ptr(b_h), b_o, B, D, H,
+                                             float(beta_eff), ptr(lin), current_stream()), "qbm_qbm_linear_fields")
+        return lin
+
+
+class HipGibbsSampler:
+    """Drop-in for src/qubo/sampler.py::LocalSASampler (same constructor keywords, same sample_Q)."""
+
+    def __init__(self, num_sweeps: int = 1000, seed: int | None = None, beta_range=(0.1, 4.0), device="cuda:0"):
+        self.ops = HipQuboOps(device)
+        self.num_sweeps = int(num_sweeps)
+        self.seed = 0 if seed is None else int(seed)
+        self.beta_range = (float(beta_range[0]), float(beta_range[1]))
+        self._calls = 0
+
+    def sample_Q(self, Q: np.ndarray, num_reads: int) -> np.ndarray:
+        """Q: upper-triangular QUBO (minimise s^T Q s) -> float32 [num_reads, n] in {0,1}, column j = variable j
+        (src/qubo/sampler.py:26-33)."""
+        Q = np.asarray(Q, dtype=np.float64)
+        if Q.ndim != 2 or Q.shape[0] != Q.shape[1]:
+            raise ValueError("QUBO matrix must be square")
+        n = Q.shape[0]
+        lin = np.diag(Q).astype(np.float32)[None, :]
+        off = Q - np.diag(np.diag(Q))
+        J = (off + off.T).astype(np.float32)
+        states, _ = self.ops.gibbs(torch.from_numpy(lin), torch.from_numpy(J), int(num_reads), self.num_sweeps,
+                                   self.beta_range[0], self.beta_range[1], self.seed, self._calls << 20,
+                                   want_mean=False)
+        self._calls += 1
+        return states[0].to(torch.float32).cpu().numpy()

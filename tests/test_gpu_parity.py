@@ -1,0 +1,267 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+the CPU oracle on the same seeded inputs.  Bar: bit-exact for sampled bits AND for every fp32 value
+(the numerical contract makes the two sides perform the same IEEE operations in the same order);
+against the reference's golden vectors the tolerances of SURVEY.md 8.D apply."""
+import numpy as np
+import pytest
+
+from helpers import golden, rel_err, synth_inputs, synth_params
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+SHAPES = [  # (V, H, C, B)
+    (16, 8, 2, 6),        # Bars-and-Stripes size (config #1)
+    (13, 9, 3, 5),        # nothing aligned: scalar guarded paths
+    (784, 9, 2, 7),       # rbm_main.py defaults (H=9, batch 7)
+    (784, 128, 2, 128),   # config #2
+    (784, 512, 10, 256),  # config #3/#4 per-GPU shape
+    (784, 512, 2, 33),    # ragged last strip
+    (100, 260, 4, 1),     # single row
+]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from qbm_image_classification_amd.rbm_ops import HipRbmOps
+
+    return HipRbmOps("cuda:0")  # raises if the HIP library or the GPU is missing
+
+
+def P_of(ops, W, b, d, U, c):
+    from qbm_image_classification_amd.rbm_ops import ParamSet
+
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(ops.device)
+    return ParamSet(t(W), t(b), t(d), t(U), t(c))
+
+
+def dev(ops, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(ops.device)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_bitwise(got, want, what):
+    got = got.detach().cpu().numpy() if hasattr(got, "detach") else np.asarray(got)
+    bad = bits(got) != bits(want)
+    assert not bad.any(), f"{what}: {bad.sum()} of {bad.size} elements differ, max abs {np.abs(got - want).max()}"
+
+
+def test_native_library_is_loaded(ops):
+    import os
+
+    with open("/proc/self/maps") as f:
+        assert "libqbm_hip.so" in f.read()
+    assert os.path.exists(ops.lib._name)
+
+
+def test_device_math_bitwise(ops, oracle):
+    xs = np.concatenate([np.linspace(-100, 100, 200001), [0.0, -0.0, 88.72, 88.73, -87.0, -87.01, 1e-30, np.inf, -np.inf]])
+    xs = xs.astype(np.float32)
+    for which in ("exp", "sigmoid", "softplus"):
+        assert_bitwise(ops.math(which, dev(ops, xs)), oracle.math(which, xs), which)
+    xl = np.concatenate([np.exp(np.linspace(-40, 88, 200001)), [0.0, 1.0, np.inf, 2.0 ** -24, 1 - 2.0 ** -24]]).astype(np.float32)
+    assert_bitwise(ops.math("log", dev(ops, xl)), oracle.math("log", xl), "log")
+
+
+def test_philox_uniform_bitwise(ops, oracle):
+    for seed, off, row0, r, c in [(0, 0, 0, 4, 8), ((7 << 32) | 5, (3 << 32) | 9, 11, 33, 130), (2 ** 64 - 1, 2 ** 63, 2 ** 32 - 2, 3, 7)]:
+        assert_bitwise(ops.uniform(seed, off, row0, r, c), oracle.philox_uniform(seed, off, row0, r, c), "uniform")
+
+
+@pytest.mark.parametrize("V,H,C,B", SHAPES)
+def test_conditionals_bitwise(ops, oracle, V, H, C, B):
+    W, b, d, U, c = synth_params(V, H, C, 100 + V + H)
+    v_bin, x_grey, h_bin, labels, y1h = synth_inputs(B, V, H, C, 7)
+    P = P_of(ops, W, b, d, U, c)
+    seed, off, row0 = 0x1234567887654321, 42, 1000
+    for v in (v_bin, x_grey):
+        p, s = ops.sample_hidden(P, dev(ops, v), dev(ops, y1h), seed, off, row0, True, True)
+        po, so = oracle.rbm_sample_hidden(v, y1h, W, d, U, seed, off, row0)
+        assert_bitwise(p, po, "p(h|v,y)")
+        assert_bitwise(s, so, "h sample")
+    p, _ = ops.sample_hidden(P, dev(ops, v_bin), None)
+    assert_bitwise(p, oracle.rbm_sample_hidden(v_bin, None, W, d, U, sample=False)[0], "p(h|v)")
+    assert_bitwise(ops.hidden_preact(P, dev(ops, x_grey)), oracle.rbm_free_energy(x_grey, W, d, U, c)[0], "x.W + d")
+    p, s = ops.sample_visible(P, dev(ops, h_bin), seed, off + 1, row0, True, True)
+    po, so = oracle.rbm_sample_visible(h_bin, W, b, seed, off + 1, row0)
+    assert_bitwise(p, po, "p(v|h)")
+    assert_bitwise(s, so, "v sample")
+    p, s = ops.sample_class(P, dev(ops, h_bin), seed, off + 2, row0, True, True)
+    po, so = oracle.rbm_sample_class(h_bin, U, c, seed, off + 2, row0)
+    assert_bitwise(p, po, "p(y|h)")
+    assert_bitwise(s, so, "y sample")
+    assert (s.sum(1) == 1).all()
+
+
+@pytest.mark.parametrize("V,H,C,B", SHAPES)
+def test_free_energy_bitwise(ops, oracle, V, H, C, B):
+    W, b, d, U, c = synth_params(V, H, C, 200 + V + H)
+    _, x_grey, *_ = synth_inputs(B, V, H, C, 8)
+    nf, p = ops.free_energy(P_of(ops, W, b, d, U, c), dev(ops, x_grey))
+    _, nfo, po = oracle.rbm_free_energy(x_grey, W, d, U, c)
+    assert_bitwise(nf, nfo, "-F")
+    assert_bitwise(p, po, "p(y|x)")
+
+
+@pytest.mark.parametrize("name", ["small", "mid", "big"])
+def test_against_reference_golden(ops, name):
+    """HIP vs the imported reference's outputs (tools/make_golden.py), SURVEY.md 8.D tolerances."""
+    g = golden(f"rbm_prims_{name}.npz")
+    V, H, C, B, seed = (int(g[k]) for k in ("V", "H", "C", "B", "seed"))
+    W, b, d, U, c = synth_params(V, H, C, seed)
+    v_bin, x_grey, h_bin, labels, y1h = synth_inputs(B, V, H, C, seed)
+    P = P_of(ops, W, b, d, U, c)
+    cpu = lambda t: t.cpu().numpy()
+    assert np.max(np.abs(cpu(ops.sample_hidden(P, dev(ops, v_bin), dev(ops, y1h))[0]) - g["ph_bin"])) <= 1e-6
+    assert np.max(np.abs(cpu(ops.sample_hidden(P, dev(ops, x_grey), dev(ops, y1h))[0]) - g["ph_grey"])) <= 1e-6
+    assert np.max(np.abs(cpu(ops.sample_visible(P, dev(ops, h_bin))[0]) - g["pv"])) <= 1e-6
+    assert np.max(np.abs(cpu(ops.sample_class(P, dev(ops, h_bin))[0]) - g["py"])) <= 1e-6
+    for x, tag in ((x_grey, "grey"), (v_bin, "bin")):
+        nf, p = ops.free_energy(P, dev(ops, x))
+        assert rel_err(cpu(nf), g[f"negF_{tag}"]) <= 1e-5      # free energy: 1e-5 relative (north_star)
+        assert rel_err(cpu(nf), g[f"negF_{tag}_f64"]) <= 1e-5
+        assert np.array_equal(cpu(p).argmax(1), g[f"pyx_{tag}"].argmax(1))  # identical argmax labels
+        assert np.max(np.abs(cpu(p) - g[f"pyx_{tag}"])) <= 2e-4
+
+
+@pytest.mark.parametrize("V,H,C,B", SHAPES)
+def test_discriminative_step_bitwise(ops, oracle, V, H, C, B):
+    from qbm_image_classification_amd.rbm_ops import GradSet
+
+    W, b, d, U, c = synth_params(V, H, C, 300 + V + H)
+    _, x_grey, _, labels, _ = synth_inputs(B, V, H, C, 9)
+    for fuse in (False, True):
+        P = P_of(ops, W, b, d, U, c)
+        G = GradSet(V, H, C, ops.device)
+        p = ops.disc_step(P, G, dev(ops, x_grey), torch.from_numpy(labels), True, fuse, 0.05, 1.0, float(B), 0.001)
+        gW, gd, gU, gc, po, _ = oracle.rbm_disc_grad(x_grey, labels, W, d, U, c)
+        assert_bitwise(p, po, "p(y|x)")
+        if not fuse:
+            assert_bitwise(G.gW, gW, "gW")
+        assert_bitwise(G.gd, gd, "gd")
+        assert_bitwise(G.gU, gU, "gU")
+        assert_bitwise(G.gc, gc, "gc")
+        Wn, bn, dn, Un, cn = (a.copy() for a in (W, b, d, U, c))
+        oracle.rbm_update(Wn, bn, dn, Un, cn, gW, None, gd, gU, gc, 0.05, 1.0, float(B), 0.001)
+        for got, want, nm in ((P.W, Wn, "W"), (P.b, bn, "b"), (P.d, dn, "d"), (P.U, Un, "U"), (P.c, cn, "c")):
+            assert_bitwise(got, want, f"{nm} after update (fuse={fuse})")
+
+
+@pytest.mark.parametrize("V,H,C,B,k,pcd", [(16, 8, 2, 6, 1, False), (13, 9, 3, 5, 2, True), (784, 128, 2, 128, 1, False),
+                                           (784, 512, 10, 256, 1, False), (784, 512, 10, 64, 3, True)])
+def test_cd_step_bitwise(ops, oracle, V, H, C, B, k, pcd):
+    from qbm_image_classification_amd.rbm_ops import GradSet
+
+    W, b, d, U, c = synth_params(V, H, C, 400 + V + H)
+    v_bin, _, _, labels, y1h = synth_inputs(B, V, H, C, 10)
+    seed, off, row0 = 99, 1000, 512
+    cv = (np.roll(v_bin, 1, axis=0).copy(), np.roll(y1h, 1, axis=0).copy()) if pcd else (None, None)
+    ph0, vk, yk, phk = oracle.rbm_cd_chain(v_bin, y1h, W, b, d, U, c, k, seed, off, row0,
+                                           None if not pcd else cv[0], None if not pcd else cv[1])
+    gW, gb, gd, gU, gc = oracle.rbm_two_phase_grad(v_bin, y1h, ph0, vk, yk, phk)
+    for fuse in (False, True):
+        P = P_of(ops, W, b, d, U, c)
+        G = GradSet(V, H, C, ops.device)
+        chain_v = dev(ops, np.roll(v_bin, 1, axis=0)) if pcd else None
+        chain_y = dev(ops, np.roll(y1h, 1, axis=0)) if pcd else None
+        ws = ops.cd_step(P, G, dev(ops, v_bin), dev(ops, y1h), k, seed, off, row0, chain_v, chain_y, fuse, 0.05, 1.0,
+                         float(B), 0.0)
+        assert_bitwise(ws[0], ph0, "p(h0)")
+        assert_bitwise(ws[2], vk, "v_k")
+        assert_bitwise(ws[3], yk, "y_k")
+        assert_bitwise(ws[4], phk, "p(h_k)")
+        if pcd:
+            assert_bitwise(chain_v, cv[0], "persistent v")
+            assert_bitwise(chain_y, cv[1], "persistent y")
+        if not fuse:
+            assert_bitwise(G.gW, gW, "gW")
+        for got, want, nm in ((G.gb, gb, "gb"), (G.gd, gd, "gd"), (G.gU, gU, "gU"), (G.gc, gc, "gc")):
+            assert_bitwise(got, want, nm)
+        if fuse:
+            Wn, bn, dn, Un, cn = (a.copy() for a in (W, b, d, U, c))
+            oracle.rbm_update(Wn, bn, dn, Un, cn, gW, gb, gd, gU, gc, 0.05, 1.0, float(B), 0.0)
+            for got, want, nm in ((P.W, Wn, "W"), (P.b, bn, "b"), (P.d, dn, "d"), (P.U, Un, "U"), (P.c, cn, "c")):
+                assert_bitwise(got, want, f"{nm} after fused update")
+
+
+def test_sharding_invariance_full_size(ops):
+    """Size-independent property at the benchmark shape: sampling rows [0,256) in one call equals two
+    calls on the halves with row0 = 0 / 128 (what two data-parallel ranks would do), bit for bit."""
+    V, H, C, B = 784, 512, 10, 256
+    W, b, d, U, c = synth_params(V, H, C, 5)
+    v_bin, _, h_bin, labels, y1h = synth_inputs(B, V, H, C, 11)
+    P = P_of(ops, W, b, d, U, c)
+    v, y, h = dev(ops, v_bin), dev(ops, y1h), dev(ops, h_bin)
+    for fn, args in ((ops.sample_hidden, (v, y)), (ops.sample_visible, (h,)), (ops.sample_class, (h,))):
+        p, s = fn(P, *args, 17, 3, 0, True, True)
+        halves = [fn(P, *(a[i:i + 128] for a in args), 17, 3, i, True, True) for i in (0, 128)]
+        assert torch.equal(p, torch.cat([t[0] for t in halves]))
+        assert torch.equal(s, torch.cat([t[1] for t in halves]))
+    p2, s2 = ops.sample_hidden(P, v, y, 17, 3, 0, True, True)
+    p1, s1 = ops.sample_hidden(P, v, y, 17, 3, 0, True, True)
+    assert torch.equal(p1, p2) and torch.equal(s1, s2)           # idempotent / deterministic
+    _, s3 = ops.sample_hidden(P, v, y, 17, 4, 0, True, True)
+    assert not torch.equal(s1, s3)                               # a new draw id gives new bits
+    assert abs(float(s1.mean()) - float(p1.mean())) < 5e-3       # Bernoulli mean matches the probabilities
+
+
+def test_edge_cases(ops):
+    from qbm_image_classification_amd._lib import QbmHipError
+    from qbm_image_classification_amd.rbm_ops import ParamSet
+
+    W, b, d, U, c = synth_params(16, 8, 2, 1)
+    P = P_of(ops, W, b, d, U, c)
+    p, s = ops.sample_hidden(P, torch.zeros(0, 16, device=ops.device), None, 0, 0, 0, True, True)  # empty batch
+    assert p.shape == (0, 8) and s.shape == (0, 8)
+    import ctypes as C
+
+    ps = P.struct()
+    rc = ops.lib.qbm_rbm_sample_hidden(C.byref(ps), None, None, 4, None, None, 0, 0, 0, None)  # null buffers
+    assert rc == -1 and b"null" in ops.lib.qbm_last_error()
+    rc = ops.lib.qbm_rbm_sample_hidden(C.byref(ps), None, None, -3, None, None, 0, 0, 0, None)
+    assert rc == -1
+    big = synth_params(8, 4, 40, 2)  # C > QBM_MAX_CLASSES
+    with pytest.raises(QbmHipError):
+        ops.sample_class(P_of(ops, *big), torch.zeros(2, 4, device=ops.device))
+    # saturated activations: probabilities exactly 0/1, free energy overflows to inf like the reference
+    Wb = np.full((16, 8), 50.0, np.float32)
+    Pb = P_of(ops, Wb, b, d, U, c)
+    ph, sh = ops.sample_hidden(Pb, torch.ones(3, 16, device=ops.device), None, 1, 1, 0, True, True)
+    assert (ph == 1).all() and (sh == 1).all()
+    nf, _ = ops.free_energy(Pb, torch.ones(3, 16, device=ops.device))
+    assert torch.isinf(nf).all()
+
+
+def test_qubo_gibbs_bitwise(oracle):
+    from qbm_image_classification_amd.sampler import HipQuboOps
+
+    q = HipQuboOps("cuda:0")
+    rs = np.random.RandomState(3)
+    for (B, R, n, sweeps, b0, b1) in [(3, 5, 7, 4, 1.0, 1.0), (2, 10, 65, 6, 0.1, 3.0), (4, 7, 257, 3, 1.0, 1.0),
+                                      (1, 3, 300, 2, 0.5, 2.0), (2, 4, 1, 3, 1.0, 1.0)]:
+        lin = rs.standard_normal((B, n)).astype(np.float32)
+        Ju = np.triu(rs.standard_normal((n, n)).astype(np.float32) * 0.3, 1)
+        J = (Ju + Ju.T).astype(np.float32)
+        st, mean = q.gibbs(torch.from_numpy(lin).cuda(), torch.from_numpy(J).cuda(), R, sweeps, b0, b1, 77, 5)
+        so, mo = oracle.qubo_gibbs(lin, J, R, sweeps, b0, b1, 77, 5)
+        assert np.array_equal(st.cpu().numpy(), so), f"states differ for n={n}"
+        assert_bitwise(mean, mo, "mean over reads")
+
+
+def test_qbm_linear_fields_bitwise(oracle):
+    from qbm_image_classification_amd.sampler import HipQuboOps
+
+    q = HipQuboOps("cuda:0")
+    g = golden("qbm_small.npz")
+    X, Y = g["X"], g["Y"]
+    for labels in (None, Y):
+        lin = q.linear_fields(X, labels, g["W_vh"], g["W_vo"], g["b_h"], g["b_o"], float(g["beta_eff"]))
+        want = oracle.qbm_linear_fields(X, labels, g["W_vh"], g["W_vo"], g["b_h"], g["b_o"], float(g["beta_eff"]))
+        assert_bitwise(lin, want, "linear fields")
+        Q = g["Q_clamped"] if labels is not None else g["Q_unclamped"]
+        diag = np.stack([np.diag(Q[i]) for i in range(len(X))])
+        assert np.max(np.abs(lin.cpu().numpy() - diag)) <= 1e-6 * max(1.0, np.abs(diag).max())  # vs the reference's Q
