@@ -1,0 +1,259 @@
+#!/usr/bin/env python
+"""bench.py -- Gibbs samples/s of the CD-1 hot path (BASELINE.json metric) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): ClassificationRBM 784 visible x 512 hidden, C = 10, CD-1, minibatch 256
+PER GPU (weak scaling; with N ranks the global batch is 256*N and one RCCL all-reduce of the flat
+gradient buffer precedes the update, BASELINE.json configs[3]).  A "step" = one full CD-1 update:
+h0 ~ p(h|v0,y0); v1 ~ p(v|h0); y1 ~ p(y|h0); p(h|v1,y1); two-phase gradient; parameter update.
+Inputs are synthetic (Philox Bernoulli(0.5) visibles, uniform labels, reference init) and resident in
+HBM before the timed region.  value = B * k * steps * N / time  (Gibbs samples/s, one sample = one
+full block-Gibbs sweep of one chain); visible-unit updates/s = 784 * value is printed alongside.
+
+The JSON line also carries `roofline` (dominant kernel, HIP-event timed inside this process) and
+`cpu_baseline` (the oracle -- a C/OpenMP restatement of the same algorithm -- on the host cores,
+rank 0, N = 1 only, bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+V, H, NC, B, K_CD = 784, 512, 10, 256, 1
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0          # ibid., HBM3E spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--graph", type=int, default=8, help="steps captured per hipGraph (0 = eager launches)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from qbm_image_classification_amd import _lib
+    from qbm_image_classification_amd.rbm_ops import GradSet, HipRbmOps, ParamSet
+    from qbm_image_classification_amd._lib import CdWorkspace, check, ptr
+
+    ops = HipRbmOps(str(dev))
+    lib = ops.lib
+
+    # ---- parameters: reference init (src/ClassificationRBM.py:26-30), torch seed 42 ----------------
+    torch.manual_seed(42)
+    P = ParamSet((torch.randn(V, H) * 0.1).to(dev), (torch.ones(V) * 0.5).to(dev), torch.zeros(H, device=dev),
+                 torch.zeros(NC, H, device=dev), torch.zeros(NC, device=dev))
+    G = GradSet(V, H, NC, dev)
+    lr, factor, sparse = 0.05, 1.0, 0.0
+
+    # ---- synthetic minibatches, resident in HBM ----------------------------------------------------
+    NB = max(8, args.graph if args.graph > 0 else 8)
+    row_base = rank * B
+    data_v, data_y = [], []
+    for i in range(NB):
+        u = ops.uniform(1234, i, row_base, B, V)
+        data_v.append((u < 0.5).float().contiguous())
+        ul = ops.uniform(4321, i, row_base, B, 1).view(-1)
+        lab = torch.clamp((ul * NC).long(), max=NC - 1)
+        data_y.append(torch.nn.functional.one_hot(lab, NC).float().contiguous())
+    ws = ops.cd_workspace(P, B)
+    cws = CdWorkspace(*(ptr(t) for t in ws))
+    ps, gs = P.struct(), G.struct()
+    global_B = float(B * world)
+
+    def step(i, stream):
+        """one CD-1 update on resident minibatch i % NB"""
+        j = i % NB
+        off = 4 * i
+        if world == 1:
+            check(lib.qbm_rbm_cd_step(C.byref(ps), C.byref(gs), ptr(data_v[j]), ptr(data_y[j]), B, K_CD, 42, off,
+                                      row_base, None, None, C.byref(cws), 1, lr, factor, global_B, sparse, stream),
+                  "qbm_rbm_cd_step")
+        else:
+            check(lib.qbm_rbm_cd_step(C.byref(ps), C.byref(gs), ptr(data_v[j]), ptr(data_y[j]), B, K_CD, 42, off,
+                                      row_base, None, None, C.byref(cws), 0, lr, factor, global_B, sparse, stream),
+                  "qbm_rbm_cd_step")
+            dist.all_reduce(G.flat, op=dist.ReduceOp.SUM)          # RCCL over xGMI, one collective per step
+            check(lib.qbm_rbm_update(C.byref(ps), C.byref(gs), lr, factor, global_B, sparse, stream), "qbm_rbm_update")
+
+    def cur():
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    graphs = None
+    if args.graph > 0 and world == 1:
+        # S consecutive steps (S resident minibatches) per hipGraph: amortises host launch cost
+        S = args.graph
+        for i in range(S):                                           # eager warm-up of every code path
+            step(i, cur())
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for i in range(S):
+                step(i, cur())
+        graphs = (g, S)
+
+    def run(nsteps):
+        if graphs is None:
+            for i in range(nsteps):
+                step(i, cur())
+        else:
+            g, S = graphs
+            for _ in range(nsteps // S):
+                g.replay()
+            for i in range(nsteps % S):
+                step(i, cur())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(P.W).all(), "parameters diverged"
+
+    ms_per_step = dt / args.steps * 1e3
+    value = B * K_CD * args.steps * world / dt
+
+    # ---- roofline: per-kernel launch duration with HIP events on the launching stream ---------------
+    def time_kernel(fn, reps=200):
+        st = torch.cuda.current_stream()
+        for _ in range(20):
+            fn(cur())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(reps):
+            fn(cur())
+        e1.record(st)
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    roofline = None
+    if rank == 0:
+        v0, y0 = data_v[0], data_y[0]
+        ph0, h, vk, yk, phk = ws
+        ng = _lib.RbmGrads(None, ptr(G.gb), ptr(G.gd), ptr(G.gU), ptr(G.gc))
+        scratchW = P.W.clone()
+        kernels = {
+            # name: (launcher, algorithmic FLOPs per launch, launches per CD-1 step)
+            "k_hidden (sample_hidden, x2 per step)": (
+                lambda s: lib.qbm_rbm_sample_hidden(C.byref(ps), ptr(v0), ptr(y0), B, ptr(ph0), ptr(h), 42, 0, 0, s),
+                2.0 * B * V * H + 2.0 * B * NC * H, 2),
+            "k_visible (sample_visible)": (
+                lambda s: lib.qbm_rbm_sample_visible(C.byref(ps), ptr(h), B, None, ptr(vk), 42, 1, 0, s),
+                2.0 * B * V * H, 1),
+            "k_grad (two-phase gradient + fused W update)": (
+                lambda s: lib.qbm_rbm_two_phase_grad(V, H, NC, B, ptr(v0), ptr(y0), ptr(ph0), ptr(vk), ptr(yk), ptr(phk),
+                                                     C.byref(ng), ptr(scratchW), None, lr, factor, global_B, sparse, s),
+                4.0 * B * V * H + 4.0 * B * NC * H, 1),
+        }
+        timed = {k: time_kernel(f) for k, (f, _, _) in kernels.items()}
+        dom = max(timed, key=lambda k: timed[k] * kernels[k][2])
+        fl = kernels[dom][1]
+        ach = fl / timed[dom] / 1e12
+        alg_bytes = 4.0 * B * V + 8.0 * (V * H + V + H + NC * H + NC) + 4.0 * B    # SURVEY.md 8.D, per CD-1 step
+        roofline = {
+            "bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "avg_launch_us": round(timed[dom] * 1e6, 3),
+            "all_kernels_us": {k: round(t * 1e6, 3) for k, t in timed.items()},
+            "step_flops": (4 * K_CD + 6) * B * V * H + (4 * K_CD + 6) * B * NC * H,
+            "step_achieved_tflops": round(((4 * K_CD + 6) * B * (V + NC) * H) / (dt / args.steps) / 1e12, 3),
+            "step_algorithmic_hbm_bytes": alg_bytes,
+            "step_hbm_frac_of_8TBs": round(alg_bytes / (dt / args.steps) / 1e9 / PEAK_HBM_GBS, 5),
+        }
+
+    # ---- CPU baseline: the oracle (C/OpenMP restatement) on the host cores, bounded sample ----------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.cpu_seconds)
+
+    if rank == 0:
+        out = {
+            "metric": "gibbs_samples_per_sec", "value": round(value, 1), "unit": "samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ClassificationRBM 784v x 512h, C=10, CD-1, batch 256 per GPU (BASELINE.json configs[3] shape; "
+                                   "global batch 256*N, RCCL all-reduce of the flat gradient per step when N>1)",
+                       "batch_per_gpu": B, "cd_k": K_CD, "launch": f"hipGraph x{graphs[1]} steps" if graphs else "eager"},
+            "visible_unit_updates_per_sec": round(value * V, 1),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(budget_s: float):
+    """Same CD-1 step (same shapes, same Philox stream) on the oracle; `cores` = OpenMP threads used."""
+    import numpy as np
+
+    from oracle import qbm_oracle as orc
+
+    orc.build()
+    rs = np.random.RandomState(42)
+    W = (rs.standard_normal((V, H)) * 0.1).astype(np.float32)
+    b = np.full(V, 0.5, np.float32)
+    d = np.zeros(H, np.float32)
+    U = np.zeros((NC, H), np.float32)
+    c = np.zeros(NC, np.float32)
+    v0 = (orc.philox_uniform(1234, 0, 0, B, V) < 0.5).astype(np.float32)
+    lab = np.minimum((orc.philox_uniform(4321, 0, 0, B, 1).reshape(-1) * NC).astype(np.int64), NC - 1)
+    y0 = np.eye(NC, dtype=np.float32)[lab]
+
+    def one(i):
+        ph0, vk, yk, phk = orc.rbm_cd_chain(v0, y0, W, b, d, U, c, K_CD, 42, 4 * i, 0)
+        g = orc.rbm_two_phase_grad(v0, y0, ph0, vk, yk, phk)
+        orc.rbm_update(W, b, d, U, c, *g, 0.05, 1.0, float(B), 0.0)
+
+    one(0)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        one(n + 1)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(B * K_CD * n / dt, 1), "unit": "samples/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
+            "sample": f"{n} CD-1 steps of the same 784x512, B=256 workload in {dt:.1f} s (oracle/qbm_oracle.c, OpenMP)",
+            "ms_per_step": round(dt / n * 1e3, 3)}
+
+
+if __name__ == "__main__":
+    main()

@@ -83,6 +83,12 @@ QBM_API int qbm_rbm_hidden_preact(const qbm_rbm_params* P, const float* x, int B
 QBM_API int qbm_rbm_sample_visible(const qbm_rbm_params* P, const float* h, int B, float* p_v, float* v_sample,
                                    uint64_t seed, uint64_t offset, uint32_t row0, void* stream);
 
+/* sample_visible and sample_class of the same hidden state in ONE launch (the class conditional rides
+ * along as extra workgroups): what a Gibbs step h -> (v, y) needs. */
+QBM_API int qbm_rbm_sample_visible_class(const qbm_rbm_params* P, const float* h, int B, float* p_v,
+                                         float* v_sample, float* p_y, float* y1hot, uint64_t seed,
+                                         uint64_t offset_v, uint64_t offset_y, uint32_t row0, void* stream);
+
 /* ClassificationRBM.sample_class, src/ClassificationRBM.py:54-60: exp(h.U^T + c), L1-normalised.
  * p_y[B,C] and/or a categorical one-hot draw y1hot[B,C]. */
 QBM_API int qbm_rbm_sample_class(const qbm_rbm_params* P, const float* h, int B, float* p_y, float* y1hot,
@@ -112,10 +118,12 @@ QBM_API int qbm_rbm_disc_class_grad(const qbm_rbm_params* P, const float* pre, c
  *   gb = colsum(A0) - colsum(A1),  gc = colsum(Y0) - colsum(Y1)
  * A*[B,V], Y*[B,C] (NULL = zeros), P*[B,H].  Outputs as selected by the non-NULL fields of G.
  * W_fused non-NULL: additionally W += factor*gW*lr/batch_size in the same pass
- * (src/ClassificationRBM.py:90); gW itself may then be NULL. */
+ * (src/ClassificationRBM.py:90); gW itself may then be NULL.  aux_fused non-NULL: its b, d, U, c blocks
+ * are updated in the same launch as well (:91-99, including the sparse_constant subtraction). */
 QBM_API int qbm_rbm_two_phase_grad(int V, int H, int C, int B, const float* A0, const float* Y0, const float* P0,
                                    const float* A1, const float* Y1, const float* P1, const qbm_rbm_grads* G,
-                                   float* W_fused, float lr, float factor, float batch_size, void* stream);
+                                   float* W_fused, const qbm_rbm_params* aux_fused, float lr, float factor,
+                                   float batch_size, float sparse_constant, void* stream);
 
 /* ClassificationRBM.update_weights, src/ClassificationRBM.py:88-99:
  * theta += factor*grad*lr/batch_size; b, d, c -= sparse_constant.  G->gW == NULL skips W (already

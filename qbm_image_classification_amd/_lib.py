@@ -52,7 +52,8 @@ SIGNATURES = {
     "qbm_rbm_free_energy": [_PP, _p, _i, _p, _p, _p, _p],
     "qbm_rbm_disc_terms": [_PP, _p, _p, _p, _i, _p, _p, _p, _p],
     "qbm_rbm_disc_class_grad": [_PP, _p, _p, _p, _i, _p, _p, _p],
-    "qbm_rbm_two_phase_grad": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _GP, _p, _f, _f, _f, _p],
+    "qbm_rbm_two_phase_grad": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _GP, _p, _PP, _f, _f, _f, _f, _p],
+    "qbm_rbm_sample_visible_class": [_PP, _p, _i, _p, _p, _p, _p, _u64, _u64, _u64, _u32, _p],
     "qbm_rbm_update": [_PP, _GP, _f, _f, _f, _f, _p],
     "qbm_rbm_cd_chain": [_PP, _p, _p, _i, _i, _u64, _u64, _u32, _p, _p, C.POINTER(CdWorkspace), _p],
     "qbm_rbm_cd_step": [_PP, _GP, _p, _p, _i, _i, _u64, _u64, _u32, _p, _p, C.POINTER(CdWorkspace), _i, _f, _f, _f,
@@ -76,6 +77,10 @@ def load() -> C.CDLL:
         raise QbmHipError(
             f"{SO} not found: build the HIP extension first (python -m qbm_image_classification_amd.build). "
             "There is no CPU fallback for this path.")
+    # torch must map its HIP runtime first: libqbm_hip.so then binds to that same libamdhip64 instance
+    # (streams and device pointers are shared with torch); loading ours first gives two runtimes.
+    import torch  # noqa: F401
+
     lib = C.CDLL(SO)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol

@@ -50,13 +50,14 @@ __device__ __forceinline__ f32x4 uniform4(uint64_t seed, uint64_t offset, uint32
 // ---------------------------------------------------------------------------------------------
 // Deterministic fp32 elementary functions (fixed operation sequences).
 // ---------------------------------------------------------------------------------------------
+// Branch-free: the polynomial is always evaluated and the special cases are selected at the end, so
+// that several independent evaluations interleave and never split the wave (same values as the
+// early-return formulation restated in the oracle).
 __device__ __forceinline__ float det_expf(float x)
 {
-    if (x != x) return x;
-    if (x > 88.72283935546875f) return __builtin_inff();
-    if (x < -87.0f) return 0.0f;
-    const float n = __builtin_rintf(x * 1.44269502162933349609375f);
-    float r = __builtin_fmaf(n, -0.693145751953125f, x);
+    const float xc = __builtin_fminf(__builtin_fmaxf(x, -87.0f), 88.72283935546875f);  // NaN -> -87: discarded below
+    const float n = __builtin_rintf(xc * 1.44269502162933349609375f);
+    float r = __builtin_fmaf(n, -0.693145751953125f, xc);
     r = __builtin_fmaf(n, -1.428606765330187045037746429443359375e-06f, r);
     float p = 1.98412701138295233249664306640625e-04f;
     p = __builtin_fmaf(p, r, 1.38888892251998186111450195312500e-03f);
@@ -70,14 +71,14 @@ __device__ __forceinline__ float det_expf(float x)
     const int h = ni / 2;
     const float s1 = __uint_as_float((uint32_t)(h + 127) << 23);
     const float s2 = __uint_as_float((uint32_t)(ni - h + 127) << 23);
-    return (p * s1) * s2;
+    float v = (p * s1) * s2;
+    v = (x > 88.72283935546875f) ? __builtin_inff() : v;
+    v = (x < -87.0f) ? 0.0f : v;
+    return (x != x) ? x : v;
 }
 
 __device__ __forceinline__ float det_logf(float x)
 {
-    if (x == 0.0f) return -__builtin_inff();
-    if (x == __builtin_inff()) return __builtin_inff();
-    if (!(x > 0.0f)) return __builtin_nanf("");
     uint32_t ix = __float_as_uint(x);
     ix += 0x3f800000u - 0x3f3504f3u;
     const int k = (int)(ix >> 23) - 0x7f;
@@ -94,7 +95,10 @@ __device__ __forceinline__ float det_logf(float x)
     float r = __builtin_fmaf(s, hfsq + R, dk * 9.0580006145e-06f);
     r = r - hfsq;
     r = r + f;
-    return __builtin_fmaf(dk, 6.9313812256e-01f, r);
+    float v = __builtin_fmaf(dk, 6.9313812256e-01f, r);
+    v = (x > 0.0f) ? v : __builtin_nanf("");
+    v = (x == __builtin_inff()) ? __builtin_inff() : v;
+    return (x == 0.0f) ? -__builtin_inff() : v;
 }
 
 // reference: src/ClassificationRBM.py:148-149  1 / (1 + exp(-x))

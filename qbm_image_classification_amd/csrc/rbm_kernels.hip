@@ -24,6 +24,15 @@ int hip_fail(hipError_t e, const char* where)
 
 namespace {
 
+// class-count buckets for the kernels that keep one register (or one float4) per class
+#define QBM_DISPATCH_CM(C, MACRO)                   \
+    do {                                            \
+        if ((C) <= 2) { MACRO(2); }                 \
+        else if ((C) <= 4) { MACRO(4); }            \
+        else if ((C) <= 10) { MACRO(10); }          \
+        else { MACRO(QBM_MAX_CLASSES); }            \
+    } while (0)
+
 // ---------------------------------------------------------------------------------------------
 // A-1  sample_hidden  (src/ClassificationRBM.py:43-47):  p = sigma(v.W + d + y.U);  h = (p > u)
 // MODE 0: probabilities (+ optional sample);  MODE 1: pre-activation v.W + d only (:65, :106).
@@ -43,7 +52,7 @@ struct HiddenArgs {
     bool vecA, vecB, vecO;
 };
 
-template <int NT, int MODE>
+template <int NT, int MODE, int CM>
 __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -57,32 +66,60 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
     if (!o.valid) return;
     const int i = m0 + o.row, j0 = n0 + 4 * o.cg;
     if (i >= a.B || j0 >= a.H) return;
+    const bool vec = a.vecO && j0 + 3 < a.H;
     const float sv[4] = {o.sum.x, o.sum.y, o.sum.z, o.sum.w};
+    // every load below is unconditional (indices clamped into range) so that they are all in flight
+    // together; classes c >= C enter the chain as fmaf(0, u, cls), which is exact
+    float dv[4], cls[4] = {0.f, 0.f, 0.f, 0.f};
+    if (vec) {
+        const float4 t = *reinterpret_cast<const float4*>(a.d + j0);
+        dv[0] = t.x; dv[1] = t.y; dv[2] = t.z; dv[3] = t.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dv[e] = a.d[min(j0 + e, a.H - 1)];
+    }
+    if (MODE == 0 && a.y) {
+        float yv[CM];
+#pragma unroll
+        for (int c = 0; c < CM; ++c) {
+            const float t = a.y[(long)i * a.C + min(c, a.C - 1)];
+            yv[c] = (c < a.C) ? t : 0.f;
+        }
+        if (vec) {
+            float4 uv[CM];
+#pragma unroll
+            for (int c = 0; c < CM; ++c) uv[c] = *reinterpret_cast<const float4*>(a.U + (long)min(c, a.C - 1) * a.H + j0);
+#pragma unroll
+            for (int c = 0; c < CM; ++c) {
+                cls[0] = __builtin_fmaf(yv[c], uv[c].x, cls[0]);
+                cls[1] = __builtin_fmaf(yv[c], uv[c].y, cls[1]);
+                cls[2] = __builtin_fmaf(yv[c], uv[c].z, cls[2]);
+                cls[3] = __builtin_fmaf(yv[c], uv[c].w, cls[3]);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CM; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    cls[e] = __builtin_fmaf(yv[c], a.U[(long)min(c, a.C - 1) * a.H + min(j0 + e, a.H - 1)], cls[e]);
+        }
+    }
     float pv[4], hv[4];
     f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
     if (MODE == 0 && a.s) u = uniform4(a.seed, a.offset, a.row0 + (uint32_t)i, (uint32_t)(j0 >> 2));
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const int j = j0 + e;
-        pv[e] = 0.f; hv[e] = 0.f;
-        if (j < a.H) {
-            float x = sv[e] + a.d[j];
-            if (MODE == 0) {
-                if (a.y) {
-                    float cls = 0.f;
-                    for (int c = 0; c < a.C; ++c)
-                        cls = __builtin_fmaf(a.y[(long)i * a.C + c], a.U[(long)c * a.H + j], cls);
-                    x = x + cls;
-                }
-                pv[e] = det_sigmoid(x);
-                hv[e] = (pv[e] > u[e]) ? 1.f : 0.f;
-            } else {
-                pv[e] = x;
-            }
+        float x = sv[e] + dv[e];
+        if (MODE == 0) {
+            if (a.y) x = x + cls[e];
+            pv[e] = det_sigmoid(x);
+            hv[e] = (pv[e] > u[e]) ? 1.f : 0.f;
+        } else {
+            pv[e] = x; hv[e] = 0.f;
         }
     }
     const long off = (long)i * a.H + j0;
-    if (a.vecO && j0 + 3 < a.H) {
+    if (vec) {
         if (a.p) *reinterpret_cast<float4*>(a.p + off) = make_float4(pv[0], pv[1], pv[2], pv[3]);
         if (MODE == 0 && a.s) *reinterpret_cast<float4*>(a.s + off) = make_float4(hv[0], hv[1], hv[2], hv[3]);
     } else {
@@ -94,8 +131,78 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
+// A-3  sample_class  (src/ClassificationRBM.py:54-60): exp(h.U^T + c), L1-normalised (eps 1e-12);
+// categorical draw: one uniform per row, first class whose running sum exceeds u.
+// One wavefront per row; the sum over j is the wave tree [T].  All loads are unconditional.
+// ---------------------------------------------------------------------------------------------
+template <int CM>
+__device__ __forceinline__ void class_row(const float* __restrict__ h, const float* __restrict__ U,
+                                          const float* __restrict__ cb, float* __restrict__ p_out,
+                                          float* __restrict__ y_out, int i, int H, int C, uint64_t seed,
+                                          uint64_t offset, uint32_t row0, int lane)
+{
+    float e[CM], cbv[CM];
+#pragma unroll
+    for (int c = 0; c < CM; ++c) { e[c] = 0.f; cbv[c] = cb[min(c, C - 1)]; }
+    // per class the lane chains j = lane, lane+64, ... ascending ([T]).  256 columns per trip: all
+    // 4 + 4*CM loads of a trip are unconditional (index clamped, h masked to 0: fmaf(0, u, e) == e)
+    for (int jb = 0; jb < H; jb += 4 * kWave) {
+        float hv[4], uv[4][CM];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int j = jb + t * kWave + lane;
+            const int jj = min(j, H - 1);
+            const float x = h[(long)i * H + jj];
+            hv[t] = (j < H) ? x : 0.f;
+#pragma unroll
+            for (int c = 0; c < CM; ++c) uv[t][c] = U[(long)min(c, C - 1) * H + jj];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int c = 0; c < CM; ++c) e[c] = __builtin_fmaf(hv[t], uv[t][c], e[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < CM; ++c) e[c] = det_expf(wave_butterfly_sum(e[c]) + cbv[c]);
+    if (lane != 0) return;
+    float denom = 0.f;
+#pragma unroll
+    for (int c = 0; c < CM; ++c)
+        if (c < C) denom = denom + __builtin_fabsf(e[c]);
+    if (!(denom > 1e-12f)) denom = 1e-12f;
+    const float u = uniform4(seed, offset, row0 + (uint32_t)i, 0u)[0];
+    float cum = 0.f;
+    int pick = C - 1;
+    bool done = false;
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+        if (c < C) {
+            const float p = e[c] / denom;
+            if (p_out) p_out[(long)i * C + c] = p;
+            cum = cum + p;
+            if (!done && u < cum) { pick = c; done = true; }
+        }
+    }
+    if (y_out)
+        for (int c = 0; c < C; ++c) y_out[(long)i * C + c] = (c == pick) ? 1.f : 0.f;
+}
+
+template <int CM>
+__global__ __launch_bounds__(256) void k_class(const float* __restrict__ h, const float* __restrict__ U,
+                                               const float* __restrict__ cb, float* __restrict__ p_out,
+                                               float* __restrict__ y_out, int B, int H, int C, uint64_t seed,
+                                               uint64_t offset, uint32_t row0)
+{
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i < B) class_row<CM>(h, U, cb, p_out, y_out, i, H, C, seed, offset, row0, threadIdx.x & 63);
+}
+
+// ---------------------------------------------------------------------------------------------
 // A-2  sample_visible  (src/ClassificationRBM.py:49-52):  p = sigma(h.W^T + b);  v = (p > u)
 // W is read as stored ([V,H], H contiguous): it is the K-contiguous B operand.
+// The launch can carry the class conditional of the same hidden state (A-3) as extra workgroups
+// appended to the grid ("aux" workgroups, 16 rows each): both read h only, so one launch serves both
+// and the tiny class product hides behind the strips.
 // ---------------------------------------------------------------------------------------------
 struct VisibleArgs {
     const float* h;  // [B,H]
@@ -108,15 +215,26 @@ struct VisibleArgs {
     uint64_t seed, offset;
     uint32_t row0;
     bool vecA, vecB, vecO;
+    // class conditional riding along (all null/0 when not wanted)
+    const float* U; const float* cb; float* py; float* ys;
+    int C; uint64_t offset_y;
+    int n_aux;  // aux workgroups come first in the grid
 };
 
-template <int NT>
+template <int NT, int CM>
 __global__ __launch_bounds__(256) void k_visible(VisibleArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if ((int)blockIdx.x < a.n_aux) {  // aux workgroup (dealt first): class conditional, 8 rows, 2 per wave
+        const int base = (int)blockIdx.x * 8 + (threadIdx.x >> 6) * 2;
+        for (int r = 0; r < 2; ++r)
+            if (base + r < a.B)
+                class_row<CM>(a.h, a.U, a.cb, a.py, a.ys, base + r, a.H, a.C, a.seed, a.offset_y, a.row0, threadIdx.x & 63);
+        return;
+    }
     const int nM = (a.B + 15) / 16, nN = (a.V + 16 * NT - 1) / (16 * NT);
     int ms, ns;
-    strip_coords(nM, nN, ms, ns);
+    strip_coords(nM, nN, ms, ns, a.n_aux);
     const int m0 = ms * 16, n0 = ns * 16 * NT;
     const ViewKContig A{a.h, a.H, a.B, a.vecA};
     const ViewKContig Bv{a.W, a.H, a.V, a.vecB};
@@ -124,20 +242,26 @@ __global__ __launch_bounds__(256) void k_visible(VisibleArgs a)
     if (!o.valid) return;
     const int i = m0 + o.row, k0 = n0 + 4 * o.cg;
     if (i >= a.B || k0 >= a.V) return;
+    const bool vec = a.vecO && k0 + 3 < a.V;
     const float sv[4] = {o.sum.x, o.sum.y, o.sum.z, o.sum.w};
+    float bv[4];
+    if (vec) {
+        const float4 t = *reinterpret_cast<const float4*>(a.b + k0);
+        bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = a.b[min(k0 + e, a.V - 1)];
+    }
     float pv[4], vv[4];
     f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
     if (a.s) u = uniform4(a.seed, a.offset, a.row0 + (uint32_t)i, (uint32_t)(k0 >> 2));
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        pv[e] = 0.f; vv[e] = 0.f;
-        if (k0 + e < a.V) {
-            pv[e] = det_sigmoid(sv[e] + a.b[k0 + e]);
-            vv[e] = (pv[e] > u[e]) ? 1.f : 0.f;
-        }
+        pv[e] = det_sigmoid(sv[e] + bv[e]);
+        vv[e] = (pv[e] > u[e]) ? 1.f : 0.f;
     }
     const long off = (long)i * a.V + k0;
-    if (a.vecO && k0 + 3 < a.V) {
+    if (vec) {
         if (a.p) *reinterpret_cast<float4*>(a.p + off) = make_float4(pv[0], pv[1], pv[2], pv[3]);
         if (a.s) *reinterpret_cast<float4*>(a.s + off) = make_float4(vv[0], vv[1], vv[2], vv[3]);
     } else {
@@ -149,47 +273,11 @@ __global__ __launch_bounds__(256) void k_visible(VisibleArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// A-3  sample_class  (src/ClassificationRBM.py:54-60): exp(h.U^T + c), L1-normalised (eps 1e-12);
-// categorical draw: one uniform per row, first class whose running sum exceeds u.
-// One wavefront per row; the sum over j is the wave tree [T].
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_class(const float* __restrict__ h, const float* __restrict__ U,
-                                               const float* __restrict__ cb, float* __restrict__ p_out,
-                                               float* __restrict__ y_out, int B, int H, int C, uint64_t seed,
-                                               uint64_t offset, uint32_t row0)
-{
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= B) return;
-    float e[QBM_MAX_CLASSES];
-    for (int c = 0; c < C; ++c) {
-        float a = 0.f;
-        for (int j = lane; j < H; j += kWave) a = __builtin_fmaf(h[(long)i * H + j], U[(long)c * H + j], a);
-        e[c] = det_expf(wave_butterfly_sum(a) + cb[c]);
-    }
-    if (lane != 0) return;
-    float denom = 0.f;
-    for (int c = 0; c < C; ++c) denom = denom + __builtin_fabsf(e[c]);
-    if (!(denom > 1e-12f)) denom = 1e-12f;
-    const float u = uniform4(seed, offset, row0 + (uint32_t)i, 0u)[0];
-    float cum = 0.f;
-    int pick = C - 1;
-    bool done = false;
-    for (int c = 0; c < C; ++c) {
-        const float p = e[c] / denom;
-        if (p_out) p_out[(long)i * C + c] = p;
-        cum = cum + p;
-        if (!done && u < cum) { pick = c; done = true; }
-    }
-    if (y_out)
-        for (int c = 0; c < C; ++c) y_out[(long)i * C + c] = (c == pick) ? 1.f : 0.f;
-}
-
-// ---------------------------------------------------------------------------------------------
 // A-4  sample_class_given_x, second half (src/ClassificationRBM.py:68-82), given pre = x.W + d:
 //   -F_y = c_y + sum_j log(1 + exp(pre_j + U_yj));   p_c = 1 / sum_d exp(-(-F_c) + (-F_d))
 // One wavefront per row, wave tree [T] over j.
 // ---------------------------------------------------------------------------------------------
+template <int CM>
 __global__ __launch_bounds__(256) void k_free_energy(const float* __restrict__ pre, const float* __restrict__ U,
                                                      const float* __restrict__ cb, float* __restrict__ negF,
                                                      float* __restrict__ p_out, int B, int H, int C)
@@ -197,18 +285,30 @@ __global__ __launch_bounds__(256) void k_free_energy(const float* __restrict__ p
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= B) return;
-    float nf[QBM_MAX_CLASSES];
-    for (int c = 0; c < C; ++c) {
-        float a = 0.f;
-        for (int j = lane; j < H; j += kWave) a = a + det_softplus(pre[(long)i * H + j] + U[(long)c * H + j]);
-        nf[c] = cb[c] + wave_butterfly_sum(a);
+    float nf[CM], cbv[CM];
+#pragma unroll
+    for (int c = 0; c < CM; ++c) { nf[c] = 0.f; cbv[c] = cb[min(c, C - 1)]; }
+    for (int j = lane; j < H; j += kWave) {
+        const float pr = pre[(long)i * H + j];
+        float uv[CM];
+#pragma unroll
+        for (int c = 0; c < CM; ++c) uv[c] = U[(long)min(c, C - 1) * H + j];
+#pragma unroll
+        for (int c = 0; c < CM; ++c) nf[c] = nf[c] + det_softplus(pr + uv[c]);
     }
+#pragma unroll
+    for (int c = 0; c < CM; ++c) nf[c] = cbv[c] + wave_butterfly_sum(nf[c]);
     if (lane != 0) return;
-    for (int c = 0; c < C; ++c) {
-        if (negF) negF[(long)i * C + c] = nf[c];
-        float s = 0.f;
-        for (int dd = 0; dd < C; ++dd) s = s + det_expf((-1.0f * nf[c]) + nf[dd]);
-        if (p_out) p_out[(long)i * C + c] = 1.0f / s;
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+        if (c < C) {
+            if (negF) negF[(long)i * C + c] = nf[c];
+            float s = 0.f;
+#pragma unroll
+            for (int dd = 0; dd < CM; ++dd)
+                if (dd < C) s = s + det_expf((-1.0f * nf[c]) + nf[dd]);
+            if (p_out) p_out[(long)i * C + c] = 1.0f / s;
+        }
     }
 }
 
@@ -275,77 +375,172 @@ __global__ __launch_bounds__(256) void k_disc_class_grad(const float* __restrict
 
 // ---------------------------------------------------------------------------------------------
 // A-5 / A-7 gradient (reference association sums: src/ClassificationRBM.py:118-138):
-//   G = [A0 | Y0 | 1]^T . [P0 | 1]  -  [A1 | Y1 | 1]^T . [P1 | 1]        (contraction over the batch)
-// rows [0,V) x cols [0,H) = gW; rows [V,V+C) = gU; row V+C = gd; col H = gb (rows < V), gc (rows V..V+C).
-// Optional fused A-6 update of W (single-GPU path; the data-parallel path all-reduces G first).
+//   gW = A0^T.P0 - A1^T.P1                                   strip workgroups (MFMA), grid part 1
+//   gU = Y0^T.P0 - Y1^T.P1, gd = colsum P0 - colsum P1        aux workgroups "H": 64 hidden columns each
+//   gb = colsum A0 - colsum A1                                aux workgroups "V": 64 visible columns each
+//   gc = colsum Y0 - colsum Y1                                aux workgroup  "C"
+// Every contraction over the batch is the quartered chain [Q]: in the aux workgroups wave q walks
+// batch quarter q with plain fmaf chains (lane = column), the four partials meet in LDS.
+// Optional fused A-6 update (src/ClassificationRBM.py:88-99): W in the strip epilogue, b/d/U/c in the
+// aux workgroups (single-GPU path; the data-parallel path all-reduces the gradients first).
 // ---------------------------------------------------------------------------------------------
 struct GradArgs {
     const float* A0; const float* Y0; const float* P0;
     const float* A1; const float* Y1; const float* P1;
     float* gW; float* gb; float* gd; float* gU; float* gc;
-    float* W;  // non-null: W += ((factor*g)*lr)/bs fused (src/ClassificationRBM.py:90)
-    float lr, factor, bs;
+    float* W;                             // non-null: fused W update
+    float* ub; float* ud; float* uU; float* uc;  // non-null: fused update of b, d, U, c in the aux workgroups
+    float lr, factor, bs, sparse;
     int B, V, H, C;
     int KP;
-    bool ones_col;
+    int n_aux, n_auxH, n_auxV;            // grid = n_aux + strips; n_aux = n_auxH + n_auxV + (gc wanted ? 1 : 0)
     bool vecA, vecP, vecO;
 };
 
-template <int NT>
+__device__ __forceinline__ float upd(float th, float g, const GradArgs& a, bool sparse)
+{
+    float t = a.factor * g;
+    t = t * a.lr;
+    t = t / a.bs;
+    th = th + t;
+    return sparse ? th - a.sparse : th;
+}
+
+template <int CM>
+__device__ __forceinline__ void grad_aux(const GradArgs& a, float* lds)
+{
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int Kq = quarter_len(a.B);
+    const int i0 = q * Kq, i1 = min(a.B, i0 + Kq);
+    int blk = (int)blockIdx.x;
+    constexpr int NACC = 2 * (CM + 1);
+    float acc[NACC];
+#pragma unroll
+    for (int t = 0; t < NACC; ++t) acc[t] = 0.f;
+    int kind, col;
+    if (blk < a.n_auxH) {          // 64 hidden columns: gd and gU[:, col]
+        kind = 0; col = blk * 64 + lane;
+        const int cc = min(col, a.H - 1);
+        // a null Y is read as zeros through stride 0 on the zero page: every load stays unconditional
+        const float* y0p = a.Y0 ? a.Y0 : g_zero16;
+        const float* y1p = a.Y1 ? a.Y1 : g_zero16;
+        const long ys0 = a.Y0 ? a.C : 0, ys1 = a.Y1 ? a.C : 0;
+        for (int ib = i0; ib < i1; ib += 64) {   // 64 batch rows per trip: lane l holds Y[ib + l, :]
+            const int ir = min(ib + lane, a.B - 1);
+            float y0r[CM], y1r[CM];
+#pragma unroll
+            for (int c = 0; c < CM; ++c) {
+                const int ci = min(c, a.C - 1);
+                y0r[c] = y0p[ir * ys0 + (a.Y0 ? ci : 0)];
+                y1r[c] = y1p[ir * ys1 + (a.Y1 ? ci : 0)];
+            }
+            const int cnt = min(64, i1 - ib);
+#pragma unroll 4
+            for (int l = 0; l < cnt; ++l) {
+                const float p0 = a.P0[(long)(ib + l) * a.H + cc], p1 = a.P1[(long)(ib + l) * a.H + cc];
+                acc[0] = __builtin_fmaf(1.0f, p0, acc[0]);
+                acc[1] = __builtin_fmaf(1.0f, p1, acc[1]);
+#pragma unroll
+                for (int c = 0; c < CM; ++c) {
+                    const float y0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y0r[c]), l));
+                    const float y1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y1r[c]), l));
+                    acc[2 + 2 * c] = __builtin_fmaf(y0, p0, acc[2 + 2 * c]);
+                    acc[3 + 2 * c] = __builtin_fmaf(y1, p1, acc[3 + 2 * c]);
+                }
+            }
+        }
+    } else if ((blk -= a.n_auxH) < a.n_auxV) {  // 64 visible columns: gb
+        kind = 1; col = blk * 64 + lane;
+        const int cc = min(col, a.V - 1);
+#pragma unroll 8
+        for (int i = i0; i < i1; ++i) {
+            acc[0] = __builtin_fmaf(a.A0[(long)i * a.V + cc], 1.0f, acc[0]);
+            acc[1] = __builtin_fmaf(a.A1[(long)i * a.V + cc], 1.0f, acc[1]);
+        }
+    } else {                        // class columns: gc
+        kind = 2; col = lane;
+        const int cc = min(col, a.C - 1);
+        const float* y0p = a.Y0 ? a.Y0 : g_zero16;
+        const float* y1p = a.Y1 ? a.Y1 : g_zero16;
+        const long ys0 = a.Y0 ? a.C : 0, ys1 = a.Y1 ? a.C : 0;
+        const int c0 = a.Y0 ? cc : 0, c1 = a.Y1 ? cc : 0;
+#pragma unroll 8
+        for (int i = i0; i < i1; ++i) {
+            acc[0] = __builtin_fmaf(y0p[i * ys0 + c0], 1.0f, acc[0]);
+            acc[1] = __builtin_fmaf(y1p[i * ys1 + c1], 1.0f, acc[1]);
+        }
+    }
+    // partials -> LDS [q][acc][lane]
+#pragma unroll
+    for (int t = 0; t < NACC; ++t) lds[(q * NACC + t) * 64 + lane] = acc[t];
+    __syncthreads();
+    if (q != 0) return;
+    float g[CM + 1];
+#pragma unroll
+    for (int t = 0; t < CM + 1; ++t) {
+        float s[2];
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            const int idx = 2 * t + ph;
+            s[ph] = ((lds[(0 * NACC + idx) * 64 + lane] + lds[(1 * NACC + idx) * 64 + lane]) + lds[(2 * NACC + idx) * 64 + lane]) +
+                    lds[(3 * NACC + idx) * 64 + lane];
+        }
+        g[t] = s[0] - s[1];
+    }
+    if (kind == 0) {
+        if (col >= a.H) return;
+        if (a.gd) a.gd[col] = g[0];
+        if (a.ud) a.ud[col] = upd(a.ud[col], g[0], a, true);
+#pragma unroll
+        for (int c = 0; c < CM; ++c) {
+            if (c < a.C) {
+                if (a.gU) a.gU[(long)c * a.H + col] = g[1 + c];
+                if (a.uU) a.uU[(long)c * a.H + col] = upd(a.uU[(long)c * a.H + col], g[1 + c], a, false);
+            }
+        }
+    } else if (kind == 1) {
+        if (col >= a.V) return;
+        if (a.gb) a.gb[col] = g[0];
+        if (a.ub) a.ub[col] = upd(a.ub[col], g[0], a, true);
+    } else {
+        if (col >= a.C) return;
+        if (a.gc) a.gc[col] = g[0];
+        if (a.uc) a.uc[col] = upd(a.uc[col], g[0], a, true);
+    }
+}
+
+template <int NT, int CM>
 __global__ __launch_bounds__(256) void k_grad(GradArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int Mx = a.V + a.C + 1, Nx = a.H + (a.ones_col ? 1 : 0);
-    const int nM = (Mx + 15) / 16, nN = (Nx + 16 * NT - 1) / (16 * NT);
+    if ((int)blockIdx.x < a.n_aux) { grad_aux<CM>(a, lds); return; }  // aux workgroups are dealt first
+    const int nM = (a.V + 15) / 16, nN = (a.H + 16 * NT - 1) / (16 * NT);
     int ms, ns;
-    strip_coords(nM, nN, ms, ns);
+    strip_coords(nM, nN, ms, ns, a.n_aux);
     const int m0 = ms * 16, n0 = ns * 16 * NT;
-    StripOut o0, o1;
-    {
-        const ViewAugData A{a.A0, a.Y0, a.V, a.C, a.vecA};
-        const ViewAugProb Bv{a.P0, a.H, a.ones_col, a.vecP};
-        o0 = strip_mma<NT, false, false>(A, Bv, m0, n0, a.B, lds, a.KP);
-    }
-    {
-        const ViewAugData A{a.A1, a.Y1, a.V, a.C, a.vecA};
-        const ViewAugProb Bv{a.P1, a.H, a.ones_col, a.vecP};
-        o1 = strip_mma<NT, false, false>(A, Bv, m0, n0, a.B, lds, a.KP);
-    }
+    const ViewCContig A0{a.A0, a.V, a.V, a.vecA}, A1{a.A1, a.V, a.V, a.vecA};
+    const ViewCContig B0{a.P0, a.H, a.H, a.vecP}, B1{a.P1, a.H, a.H, a.vecP};
+    const StripOut o0 = strip_mma<NT, false, false>(A0, B0, m0, n0, a.B, lds, a.KP);
+    const StripOut o1 = strip_mma<NT, false, false>(A1, B1, m0, n0, a.B, lds, a.KP);
     if (!o0.valid) return;
     const int m = m0 + o0.row, nb = n0 + 4 * o0.cg;
-    if (m >= Mx || nb >= Nx) return;
+    if (m >= a.V || nb >= a.H) return;
     const float g[4] = {o0.sum.x - o1.sum.x, o0.sum.y - o1.sum.y, o0.sum.z - o1.sum.z, o0.sum.w - o1.sum.w};
-    if (m < a.V && nb + 3 < a.H && a.vecO) {
-        const long off = (long)m * a.H + nb;
+    const long off = (long)m * a.H + nb;
+    if (nb + 3 < a.H && a.vecO) {
         if (a.gW) *reinterpret_cast<float4*>(a.gW + off) = make_float4(g[0], g[1], g[2], g[3]);
         if (a.W) {
             float4 w = *reinterpret_cast<const float4*>(a.W + off);
-            w.x = w.x + ((a.factor * g[0]) * a.lr) / a.bs;
-            w.y = w.y + ((a.factor * g[1]) * a.lr) / a.bs;
-            w.z = w.z + ((a.factor * g[2]) * a.lr) / a.bs;
-            w.w = w.w + ((a.factor * g[3]) * a.lr) / a.bs;
+            w.x = upd(w.x, g[0], a, false); w.y = upd(w.y, g[1], a, false);
+            w.z = upd(w.z, g[2], a, false); w.w = upd(w.w, g[3], a, false);
             *reinterpret_cast<float4*>(a.W + off) = w;
         }
         return;
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int n = nb + e;
-        if (n >= Nx) break;
-        if (n < a.H) {
-            if (m < a.V) {
-                const long off = (long)m * a.H + n;
-                if (a.gW) a.gW[off] = g[e];
-                if (a.W) a.W[off] = a.W[off] + ((a.factor * g[e]) * a.lr) / a.bs;
-            } else if (m < a.V + a.C) {
-                if (a.gU) a.gU[(long)(m - a.V) * a.H + n] = g[e];
-            } else if (a.gd) {
-                a.gd[n] = g[e];
-            }
-        } else {  // n == H: column sums of the A operand
-            if (m < a.V) { if (a.gb) a.gb[m] = g[e]; }
-            else if (m < a.V + a.C) { if (a.gc) a.gc[m - a.V] = g[e]; }
-        }
+    for (int e = 0; e < 4 && nb + e < a.H; ++e) {
+        if (a.gW) a.gW[off + e] = g[e];
+        if (a.W) a.W[off + e] = upd(a.W[off + e], g[e], a, false);
     }
 }
 
@@ -358,20 +553,20 @@ struct UpdateArgs {
     const float* gW; const float* gb; const float* gd; const float* gU; const float* gc;
     int V, H, C;
     float lr, factor, bs, sparse;
+    long first;  // first element of the concatenated range to touch (V*H when W is already updated)
 };
 
 __global__ __launch_bounds__(256) void k_update(UpdateArgs a)
 {
     const long nW = (long)a.V * a.H, nU = (long)a.C * a.H;
     const long total = nW + a.V + a.H + nU + a.C;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (long i = a.first + (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         float* th; const float* g; long k = i; bool sp = false;
         if (k < nW) { th = a.W; g = a.gW; }
         else if ((k -= nW) < a.V) { th = a.b; g = a.gb; sp = true; }
         else if ((k -= a.V) < a.H) { th = a.d; g = a.gd; sp = true; }
         else if ((k -= a.H) < nU) { th = a.U; g = a.gU; }
         else { k -= nU; th = a.c; g = a.gc; sp = true; }
-        if (th == a.W && !a.gW) continue;  // W already updated by the fused gradient epilogue
         const float gi = g ? g[k] : 0.f;   // reference: visible_bias_grad = 0 (:138)
         float t = a.factor * gi;
         t = t * a.lr;
@@ -407,7 +602,10 @@ int panel_for(int K)
 {
     const int Kq = quarter_len(K);
     int KP = (Kq + 15) / 16 * 16;
-    const int mx = strip_max_panel<NT>();
+    // LDS-DMA staging keeps (NT+1) pieces per 16 k in flight and vm_wait counts to 60
+    int mx = strip_max_panel<NT>();
+    const int by_vmcnt = (60 / (NT + 1)) * 16;
+    if (by_vmcnt < mx) mx = by_vmcnt;
     return KP < mx ? KP : mx;
 }
 
@@ -437,17 +635,82 @@ int launch_hidden(const qbm_rbm_params* P, const float* v, const float* y, int B
     constexpr int NT = 2;
     HiddenArgs a{v, y, P->W, P->d, P->U, p, s, B, P->V, P->H, P->C, panel_for<NT>(P->V), seed, offset, row0,
                  (P->V % 4 == 0) && aligned16(v), (P->H % 4 == 0) && aligned16(P->W),
-                 (P->H % 4 == 0) && (!p || aligned16(p)) && (!s || aligned16(s))};
+                 (P->H % 4 == 0) && (!p || aligned16(p)) && (!s || aligned16(s)) && aligned16(P->d) && aligned16(P->U)};
     const int nM = (B + 15) / 16, nN = (P->H + 16 * NT - 1) / (16 * NT);
     const size_t lds = sizeof(float) * strip_lds_floats<NT>(a.KP);
-    if (mode == 0) {
-        if (int rc = set_lds(k_hidden<NT, 0>, lds)) return rc;
-        hipLaunchKernelGGL((k_hidden<NT, 0>), dim3(nM * nN), dim3(256), lds, st, a);
+    if (mode != 0 || !y) {  // no class term: the class-count bucket is irrelevant
+        if (mode == 0) {
+            if (int rc = set_lds(k_hidden<NT, 0, 2>, lds)) return rc;
+            hipLaunchKernelGGL((k_hidden<NT, 0, 2>), dim3(nM * nN), dim3(256), lds, st, a);
+        } else {
+            if (int rc = set_lds(k_hidden<NT, 1, 2>, lds)) return rc;
+            hipLaunchKernelGGL((k_hidden<NT, 1, 2>), dim3(nM * nN), dim3(256), lds, st, a);
+        }
     } else {
-        if (int rc = set_lds(k_hidden<NT, 1>, lds)) return rc;
-        hipLaunchKernelGGL((k_hidden<NT, 1>), dim3(nM * nN), dim3(256), lds, st, a);
+#define QBM_L(CM)                                                                               \
+    {                                                                                           \
+        if (int rc = set_lds(k_hidden<NT, 0, CM>, lds)) return rc;                              \
+        hipLaunchKernelGGL((k_hidden<NT, 0, CM>), dim3(nM * nN), dim3(256), lds, st, a);        \
+    }
+        QBM_DISPATCH_CM(P->C, QBM_L);
+#undef QBM_L
     }
     QBM_CHECK_LAUNCH("k_hidden");
+    return QBM_OK;
+}
+
+// sample_visible, optionally with the class conditional riding along as aux workgroups
+int launch_visible(const qbm_rbm_params* P, const float* h, int B, float* p_v, float* v_sample, float* p_y,
+                   float* y1hot, uint64_t seed, uint64_t offset_v, uint64_t offset_y, uint32_t row0, hipStream_t st)
+{
+    constexpr int NT = 4;
+    const bool with_class = p_y || y1hot;
+    const int nM = (B + 15) / 16, nN = (P->V + 16 * NT - 1) / (16 * NT);
+    VisibleArgs a{h, P->W, P->b, p_v, v_sample, B, P->V, P->H, panel_for<NT>(P->H), seed, offset_v, row0,
+                  (P->H % 4 == 0) && aligned16(h), (P->H % 4 == 0) && aligned16(P->W),
+                  (P->V % 4 == 0) && (!p_v || aligned16(p_v)) && (!v_sample || aligned16(v_sample)) && aligned16(P->b),
+                  P->U, P->c, p_y, y1hot, P->C, offset_y, with_class ? (B + 7) / 8 : 0};
+    const int grid = nM * nN + a.n_aux;
+    const size_t lds = sizeof(float) * strip_lds_floats<NT>(a.KP);
+#define QBM_L(CM)                                                                         \
+    {                                                                                     \
+        if (int rc = set_lds(k_visible<NT, CM>, lds)) return rc;                          \
+        hipLaunchKernelGGL((k_visible<NT, CM>), dim3(grid), dim3(256), lds, st, a);       \
+    }
+    if (!with_class) { QBM_L(2) }
+    else { QBM_DISPATCH_CM(P->C, QBM_L); }
+#undef QBM_L
+    QBM_CHECK_LAUNCH("k_visible");
+    return QBM_OK;
+}
+
+int launch_grad(int V, int H, int C, int B, const float* A0, const float* Y0, const float* P0, const float* A1,
+                const float* Y1, const float* P1, const qbm_rbm_grads* G, float* W_fused, const qbm_rbm_params* aux_fused,
+                float lr, float factor, float bs, float sparse, hipStream_t st)
+{
+    constexpr int NT = 2;
+    const int nM = (V + 15) / 16, nN = (H + 16 * NT - 1) / (16 * NT);
+    const bool want_b = G->gb || (aux_fused && aux_fused->b);
+    const bool want_c = G->gc || (aux_fused && aux_fused->c);
+    GradArgs a{A0, Y0, P0, A1, Y1, P1, G->gW, G->gb, G->gd, G->gU, G->gc, W_fused,
+               aux_fused ? aux_fused->b : nullptr, aux_fused ? aux_fused->d : nullptr,
+               aux_fused ? aux_fused->U : nullptr, aux_fused ? aux_fused->c : nullptr,
+               lr, factor, bs, sparse, B, V, H, C, panel_for<NT>(B),
+               (H + 63) / 64 + (want_b ? (V + 63) / 64 : 0) + (want_c ? 1 : 0), (H + 63) / 64, want_b ? (V + 63) / 64 : 0,
+               (V % 4 == 0) && aligned16(A0) && aligned16(A1), (H % 4 == 0) && aligned16(P0) && aligned16(P1),
+               (H % 4 == 0) && (!G->gW || aligned16(G->gW)) && (!W_fused || aligned16(W_fused))};
+    const int grid = nM * nN + a.n_aux;
+#define QBM_L(CM)                                                                                   \
+    {                                                                                               \
+        size_t lds = sizeof(float) * strip_lds_floats<NT>(a.KP);                                    \
+        const size_t aux = sizeof(float) * 4 * 2 * (CM + 1) * 64;                                   \
+        if (aux > lds) lds = aux;                                                                   \
+        if (int rc = set_lds(k_grad<NT, CM>, lds)) return rc;                                       \
+        hipLaunchKernelGGL((k_grad<NT, CM>), dim3(grid), dim3(256), lds, st, a);                    \
+    }
+    QBM_DISPATCH_CM(C, QBM_L);
+#undef QBM_L
+    QBM_CHECK_LAUNCH("k_grad");
     return QBM_OK;
 }
 
@@ -487,16 +750,18 @@ int qbm_rbm_sample_visible(const qbm_rbm_params* P, const float* h, int B, float
     if (B < 0) return fail(QBM_ERR_ARG, "B < 0");
     if (B == 0) return QBM_OK;
     if (!h || (!p_v && !v_sample)) return fail(QBM_ERR_ARG, "sample_visible: null input/output");
-    constexpr int NT = 4;
-    VisibleArgs a{h, P->W, P->b, p_v, v_sample, B, P->V, P->H, panel_for<NT>(P->H), seed, offset, row0,
-                  (P->H % 4 == 0) && aligned16(h), (P->H % 4 == 0) && aligned16(P->W),
-                  (P->V % 4 == 0) && (!p_v || aligned16(p_v)) && (!v_sample || aligned16(v_sample))};
-    const int nM = (B + 15) / 16, nN = (P->V + 16 * NT - 1) / (16 * NT);
-    const size_t lds = sizeof(float) * strip_lds_floats<NT>(a.KP);
-    if (int rc = set_lds(k_visible<NT>, lds)) return rc;
-    hipLaunchKernelGGL((k_visible<NT>), dim3(nM * nN), dim3(256), lds, (hipStream_t)stream, a);
-    QBM_CHECK_LAUNCH("k_visible");
-    return QBM_OK;
+    return launch_visible(P, h, B, p_v, v_sample, nullptr, nullptr, seed, offset, 0, row0, (hipStream_t)stream);
+}
+
+int qbm_rbm_sample_visible_class(const qbm_rbm_params* P, const float* h, int B, float* p_v, float* v_sample,
+                                 float* p_y, float* y1hot, uint64_t seed, uint64_t offset_v, uint64_t offset_y,
+                                 uint32_t row0, void* stream)
+{
+    if (int rc = check_params(P)) return rc;
+    if (B < 0) return fail(QBM_ERR_ARG, "B < 0");
+    if (B == 0) return QBM_OK;
+    if (!h || (!p_v && !v_sample) || (!p_y && !y1hot)) return fail(QBM_ERR_ARG, "sample_visible_class: null input/output");
+    return launch_visible(P, h, B, p_v, v_sample, p_y, y1hot, seed, offset_v, offset_y, row0, (hipStream_t)stream);
 }
 
 int qbm_rbm_sample_class(const qbm_rbm_params* P, const float* h, int B, float* p_y, float* y1hot, uint64_t seed,
@@ -506,8 +771,11 @@ int qbm_rbm_sample_class(const qbm_rbm_params* P, const float* h, int B, float* 
     if (B < 0) return fail(QBM_ERR_ARG, "B < 0");
     if (B == 0) return QBM_OK;
     if (!h || (!p_y && !y1hot)) return fail(QBM_ERR_ARG, "sample_class: null input/output");
-    hipLaunchKernelGGL(k_class, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, h, P->U, P->c, p_y, y1hot, B,
-                       P->H, P->C, seed, offset, row0);
+#define QBM_L(CM)                                                                                             \
+    hipLaunchKernelGGL((k_class<CM>), dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, h, P->U, P->c, p_y, \
+                       y1hot, B, P->H, P->C, seed, offset, row0)
+    QBM_DISPATCH_CM(P->C, QBM_L);
+#undef QBM_L
     QBM_CHECK_LAUNCH("k_class");
     return QBM_OK;
 }
@@ -520,8 +788,11 @@ int qbm_rbm_free_energy(const qbm_rbm_params* P, const float* x, int B, float* p
     if (B == 0) return QBM_OK;
     if (!x || !pre_ws || (!neg_free_energy && !p_y_given_x)) return fail(QBM_ERR_ARG, "free_energy: null buffer");
     if (int rc = launch_hidden(P, x, nullptr, B, pre_ws, nullptr, 1, 0, 0, 0, (hipStream_t)stream)) return rc;
-    hipLaunchKernelGGL(k_free_energy, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, pre_ws, P->U, P->c,
-                       neg_free_energy, p_y_given_x, B, P->H, P->C);
+#define QBM_L(CM)                                                                                               \
+    hipLaunchKernelGGL((k_free_energy<CM>), dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, pre_ws, P->U,   \
+                       P->c, neg_free_energy, p_y_given_x, B, P->H, P->C)
+    QBM_DISPATCH_CM(P->C, QBM_L);
+#undef QBM_L
     QBM_CHECK_LAUNCH("k_free_energy");
     return QBM_OK;
 }
@@ -554,23 +825,16 @@ int qbm_rbm_disc_class_grad(const qbm_rbm_params* P, const float* pre, const flo
 
 int qbm_rbm_two_phase_grad(int V, int H, int C, int B, const float* A0, const float* Y0, const float* P0,
                            const float* A1, const float* Y1, const float* P1, const qbm_rbm_grads* G, float* W_fused,
-                           float lr, float factor, float batch_size, void* stream)
+                           const qbm_rbm_params* aux_fused, float lr, float factor, float batch_size,
+                           float sparse_constant, void* stream)
 {
     if (V <= 0 || H <= 0 || C <= 0 || B <= 0) return fail(QBM_ERR_ARG, "two_phase_grad: non-positive dims");
+    if (C > QBM_MAX_CLASSES) return fail(QBM_ERR_ARG, "C exceeds QBM_MAX_CLASSES");
     if (!A0 || !P0 || !A1 || !P1 || !G) return fail(QBM_ERR_ARG, "two_phase_grad: null operand");
     if (!G->gW && !W_fused) return fail(QBM_ERR_ARG, "two_phase_grad: neither gW nor fused W given");
-    constexpr int NT = 2;
-    GradArgs a{A0, Y0, P0, A1, Y1, P1, G->gW, G->gb, G->gd, G->gU, G->gc, W_fused, lr, factor, batch_size, B, V, H, C,
-               panel_for<NT>(B), (G->gb != nullptr) || (G->gc != nullptr),
-               (V % 4 == 0) && aligned16(A0) && aligned16(A1), (H % 4 == 0) && aligned16(P0) && aligned16(P1),
-               (H % 4 == 0) && (!G->gW || aligned16(G->gW)) && (!W_fused || aligned16(W_fused))};
-    const int Mx = V + C + 1, Nx = H + (a.ones_col ? 1 : 0);
-    const int nM = (Mx + 15) / 16, nN = (Nx + 16 * NT - 1) / (16 * NT);
-    const size_t lds = sizeof(float) * strip_lds_floats<NT>(a.KP);
-    if (int rc = set_lds(k_grad<NT>, lds)) return rc;
-    hipLaunchKernelGGL((k_grad<NT>), dim3(nM * nN), dim3(256), lds, (hipStream_t)stream, a);
-    QBM_CHECK_LAUNCH("k_grad");
-    return QBM_OK;
+    if ((W_fused || aux_fused) && !(batch_size > 0.f)) return fail(QBM_ERR_ARG, "two_phase_grad: batch_size must be positive");
+    return launch_grad(V, H, C, B, A0, Y0, P0, A1, Y1, P1, G, W_fused, aux_fused, lr, factor, batch_size,
+                       sparse_constant, (hipStream_t)stream);
 }
 
 int qbm_rbm_update(const qbm_rbm_params* P, const qbm_rbm_grads* G, float lr, float factor, float batch_size,
@@ -579,10 +843,12 @@ int qbm_rbm_update(const qbm_rbm_params* P, const qbm_rbm_grads* G, float lr, fl
     if (int rc = check_params(P)) return rc;
     if (!G) return fail(QBM_ERR_ARG, "update: grads is null");
     if (!(batch_size > 0.f)) return fail(QBM_ERR_ARG, "update: batch_size must be positive");
+    const long nW = (long)P->V * P->H;
+    const long total = nW + P->V + P->H + (long)P->C * P->H + P->C;
     UpdateArgs a{P->W, P->b, P->d, P->U, P->c, G->gW, G->gb, G->gd, G->gU, G->gc, P->V, P->H, P->C,
-                 lr, factor, batch_size, sparse_constant};
-    const long total = (long)P->V * P->H + P->V + P->H + (long)P->C * P->H + P->C;
-    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+                 lr, factor, batch_size, sparse_constant, G->gW ? 0 : nW};
+    const long n = total - a.first;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(k_update, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     QBM_CHECK_LAUNCH("k_update");
     return QBM_OK;
@@ -608,8 +874,8 @@ int qbm_rbm_cd_chain(const qbm_rbm_params* P, const float* v0, const float* y0, 
     }
     for (int t = 1; t <= k; ++t) {
         const uint64_t o = offset + 3ull * (uint64_t)t;
-        if (int rc = qbm_rbm_sample_visible(P, ws->h, B, nullptr, ws->vk, seed, o - 2, row0, stream)) return rc;
-        if (int rc = qbm_rbm_sample_class(P, ws->h, B, nullptr, ws->yk, seed, o - 1, row0, stream)) return rc;
+        // v_t and y_t both depend on h_{t-1} only: one launch (class conditional as aux workgroups)
+        if (int rc = launch_visible(P, ws->h, B, nullptr, ws->vk, nullptr, ws->yk, seed, o - 2, o - 1, row0, st)) return rc;
         if (int rc = launch_hidden(P, ws->vk, ws->yk, B, ws->phk, ws->h, 0, seed, o, row0, st)) return rc;
     }
     if (chain_v) {
@@ -627,17 +893,15 @@ int qbm_rbm_cd_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const float
                     float sparse_constant, void* stream)
 {
     if (!G) return fail(QBM_ERR_ARG, "cd_step: grads is null");
-    if (!G->gb || !G->gd || !G->gU || !G->gc) return fail(QBM_ERR_ARG, "cd_step: gb, gd, gU, gc are required");
-    if (!fuse_update && !G->gW) return fail(QBM_ERR_ARG, "cd_step: gW is required without fuse_update");
+    if (!fuse_update && (!G->gW || !G->gb || !G->gd || !G->gU || !G->gc))
+        return fail(QBM_ERR_ARG, "cd_step: all gradient blocks are required without fuse_update");
     if (int rc = qbm_rbm_cd_chain(P, v0, y0, B, k, seed, offset, row0, chain_v, chain_y, ws, stream)) return rc;
     if (B == 0) return QBM_OK;
+    if (!(batch_size > 0.f)) return fail(QBM_ERR_ARG, "cd_step: batch_size must be positive");
     qbm_rbm_grads g = *G;
-    if (fuse_update) g.gW = nullptr;
-    if (int rc = qbm_rbm_two_phase_grad(P->V, P->H, P->C, B, v0, y0, ws->ph0, ws->vk, ws->yk, ws->phk, &g,
-                                        fuse_update ? P->W : nullptr, lr, factor, batch_size, stream))
-        return rc;
-    if (fuse_update) return qbm_rbm_update(P, &g, lr, factor, batch_size, sparse_constant, stream);
-    return QBM_OK;
+    if (fuse_update) g.gW = nullptr;  // the whole update happens inside the gradient launch
+    return launch_grad(P->V, P->H, P->C, B, v0, y0, ws->ph0, ws->vk, ws->yk, ws->phk, &g, fuse_update ? P->W : nullptr,
+                       fuse_update ? P : nullptr, lr, factor, batch_size, sparse_constant, (hipStream_t)stream);
 }
 
 int qbm_rbm_disc_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const float* x, const int32_t* labels, int B,
@@ -651,14 +915,16 @@ int qbm_rbm_disc_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const flo
         return fail(QBM_ERR_ARG, "disc_step: null buffer");
     const bool fuse = apply_update && fuse_update;
     if (!fuse && !G->gW) return fail(QBM_ERR_ARG, "disc_step: gW is required unless the update is fused");
+    if (apply_update && !(batch_size > 0.f)) return fail(QBM_ERR_ARG, "disc_step: batch_size must be positive");
     if (int rc = qbm_rbm_free_energy(P, x, B, ws->pre, neg_free_energy, p_y, stream)) return rc;
     if (int rc = qbm_rbm_disc_terms(P, ws->pre, p_y, labels, B, ws->pos, ws->neg, ws->onehot, stream)) return rc;
     qbm_rbm_grads g = *G;
     g.gb = nullptr;  // reference: visible_bias_grad = 0 (src/ClassificationRBM.py:138)
     g.gc = nullptr;  // written by disc_class_grad below
     if (fuse) g.gW = nullptr;
-    if (int rc = qbm_rbm_two_phase_grad(P->V, P->H, P->C, B, x, ws->onehot, ws->pos, x, nullptr, ws->neg, &g,
-                                        fuse ? P->W : nullptr, lr, factor, batch_size, stream))
+    // W may be fused; U, c, d wait for disc_class_grad, so the aux workgroups only write gradients here
+    if (int rc = launch_grad(P->V, P->H, P->C, B, x, ws->onehot, ws->pos, x, nullptr, ws->neg, &g, fuse ? P->W : nullptr,
+                             nullptr, lr, factor, batch_size, sparse_constant, (hipStream_t)stream))
         return rc;
     if (int rc = qbm_rbm_disc_class_grad(P, ws->pre, p_y, labels, B, G->gU, G->gc, stream)) return rc;
     if (apply_update) {

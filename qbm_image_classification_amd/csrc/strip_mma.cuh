@@ -22,6 +22,17 @@
 
 namespace qbm {
 
+// 16 zero bytes: the LDS-DMA source of every out-of-range fragment (rows beyond M/N, k beyond the quarter)
+static __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+// LDS-DMA: 16 B per lane, global -> LDS with no VGPR destination.  The LDS address is the wave-uniform
+// `lds_piece` + lane*16; the global source is per lane (cdna_hip_programming.md section 5, Caveat).
+__device__ __forceinline__ void glds16(const float* g, float* lds_piece)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_piece, 16, 0, 0);
+}
+
 // ---- operand views: get() returns 4 consecutive elements, zero outside the operand -----------
 
 // element(row, k) = p[row*ld + k]; 4 consecutive k
@@ -30,6 +41,12 @@ struct ViewKContig {
     long ld;
     int rows;
     bool vec;  // ld % 4 == 0 and p 16-byte aligned
+    // LDS-DMA staging is legal for this strip: every float4 is wholly inside or wholly outside
+    __device__ __forceinline__ bool dma(int /*c0*/, int /*width*/, int K) const { return vec && (K & 3) == 0; }
+    __device__ __forceinline__ const float* addr(int row, int k, int kend) const
+    {
+        return (row < rows && k < kend) ? p + (long)row * ld + k : g_zero16;
+    }
     __device__ __forceinline__ float4 get(int row, int k, int kend) const
     {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -54,6 +71,11 @@ struct ViewCContig {
     long ld;
     int cols;
     bool vec;
+    __device__ __forceinline__ bool dma(int /*c0*/, int /*width*/, int /*K*/) const { return vec && (cols & 3) == 0; }
+    __device__ __forceinline__ const float* addr(int k, int c, int kend) const
+    {
+        return (k < kend && c < cols) ? p + (long)k * ld + c : g_zero16;
+    }
     __device__ __forceinline__ float4 get(int k, int c, int kend) const
     {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -79,6 +101,11 @@ struct ViewAugData {
     const float* Y;     // [B, C] or nullptr
     int V, C;
     bool vec;
+    __device__ __forceinline__ bool dma(int c0, int width, int /*K*/) const { return vec && c0 + width <= V; }
+    __device__ __forceinline__ const float* addr(int k, int m, int kend) const
+    {
+        return (k < kend) ? data + (long)k * V + m : g_zero16;
+    }
     __device__ __forceinline__ float one(int k, int m) const
     {
         if (m < V) return data[(long)k * V + m];
@@ -105,6 +132,11 @@ struct ViewAugProb {
     int H;
     bool ones;
     bool vec;
+    __device__ __forceinline__ bool dma(int c0, int width, int /*K*/) const { return vec && c0 + width <= H; }
+    __device__ __forceinline__ const float* addr(int k, int n, int kend) const
+    {
+        return (k < kend) ? P + (long)k * H + n : g_zero16;
+    }
     __device__ __forceinline__ float one(int k, int n) const
     {
         if (n < H) return P[(long)k * H + n];
@@ -139,6 +171,25 @@ struct StripOut {
     bool valid;  // this thread holds an output
 };
 
+// wait until at most n of this wave's vector-memory operations (LDS-DMA pieces included) are outstanding.
+// The compiler does not order a ds_read behind a pending LDS-DMA (only a barrier makes it drain vmcnt),
+// so every consumer of DMA-staged data sits behind one of these.
+__device__ __forceinline__ void vm_wait(int n)
+{
+#define QBM_VMW(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    switch (n) {
+        QBM_VMW(0) QBM_VMW(1) QBM_VMW(2) QBM_VMW(3) QBM_VMW(4) QBM_VMW(5) QBM_VMW(6) QBM_VMW(7) QBM_VMW(8) QBM_VMW(9)
+        QBM_VMW(10) QBM_VMW(11) QBM_VMW(12) QBM_VMW(13) QBM_VMW(14) QBM_VMW(15) QBM_VMW(16) QBM_VMW(17) QBM_VMW(18)
+        QBM_VMW(19) QBM_VMW(20) QBM_VMW(21) QBM_VMW(22) QBM_VMW(23) QBM_VMW(24) QBM_VMW(25) QBM_VMW(26) QBM_VMW(27)
+        QBM_VMW(28) QBM_VMW(29) QBM_VMW(30) QBM_VMW(31) QBM_VMW(32) QBM_VMW(33) QBM_VMW(34) QBM_VMW(35) QBM_VMW(36)
+        QBM_VMW(37) QBM_VMW(38) QBM_VMW(39) QBM_VMW(40) QBM_VMW(41) QBM_VMW(42) QBM_VMW(43) QBM_VMW(44) QBM_VMW(45)
+        QBM_VMW(46) QBM_VMW(47) QBM_VMW(48) QBM_VMW(49) QBM_VMW(50) QBM_VMW(51) QBM_VMW(52) QBM_VMW(53) QBM_VMW(54)
+        QBM_VMW(55) QBM_VMW(56) QBM_VMW(57) QBM_VMW(58) QBM_VMW(59) QBM_VMW(60)
+    default: break;  // > 60 allowed outstanding: nothing this wave has issued needs to have landed yet
+    }
+#undef QBM_VMW
+}
+
 // A_K4 / B_K4: the operand's K index is the contiguous one (k4 image), else lin image.
 //   A_K4: A.get(row, k, kend)   else A.get(k, m, kend)
 //   B_K4: B.get(col, k, kend)   else B.get(k, n, kend)
@@ -148,48 +199,71 @@ __device__ __forceinline__ StripOut strip_mma(const AView& A, const BView& Bv, i
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int q = tid >> 6;  // wave id == K quarter
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave id == K quarter (wave-uniform, SGPR)
     const int Kq = quarter_len(K);
     const int kq0 = q * Kq;
     const int kend = min(K, kq0 + Kq);
     float* img = lds + (size_t)q * (NT + 1) * 16 * KP;
-    float4* imgA4 = reinterpret_cast<float4*>(img);
 
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    const bool dmaA = A.dma(m0, 16, K), dmaB = Bv.dma(n0, 16 * NT, K);  // workgroup-uniform
     const int fragA = A_K4 ? ((lane & 15) * 4 + (lane >> 4)) : lane;
     const int fragB = B_K4 ? ((lane & 15) * 4 + (lane >> 4)) : lane;
 
-    for (int kb = kq0; kb < kq0 + Kq; kb += KP) {  // Kq is the same for all waves: uniform trip count
+    for (int kb = kq0; kb < kq0 + Kq; kb += KP) {
         const int klen = max(0, min(kend - kb, KP));
-        const int pieces = (klen + 15) >> 4;
+        const int pieces = (klen + 15) >> 4;  // 16 k per piece = 1 KiB per image = one LDS-DMA instruction
+        // ---- stage: every piece of this wave's K range is issued before anything is waited for.
+        // Issue order is piece-major (A, B_0.. of piece 0, then piece 1, ...) so that a counted vmcnt
+        // releases the pieces in the order the MFMA loop consumes them.
         for (int pc = 0; pc < pieces; ++pc) {
             const int slot = pc * 64 + lane;
-            float4 va;
-            if (A_K4) va = A.get(m0 + (slot & 15), kb + 4 * (slot >> 4), kend);
-            else      va = A.get(kb + (slot >> 2), m0 + 4 * (slot & 3), kend);
-            imgA4[slot] = va;
+            if (dmaA) {
+                const float* g = A_K4 ? A.addr(m0 + (slot & 15), kb + 4 * (slot >> 4), kend)
+                                      : A.addr(kb + (slot >> 2), m0 + 4 * (slot & 3), kend);
+                glds16(g, img + pc * 256);
+            } else {
+                float4 va;
+                if (A_K4) va = A.get(m0 + (slot & 15), kb + 4 * (slot >> 4), kend);
+                else      va = A.get(kb + (slot >> 2), m0 + 4 * (slot & 3), kend);
+                reinterpret_cast<float4*>(img)[slot] = va;
+            }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                float4 vb;
-                if (B_K4) vb = Bv.get(n0 + 16 * t + (slot & 15), kb + 4 * (slot >> 4), kend);
-                else      vb = Bv.get(kb + (slot >> 2), n0 + 16 * t + 4 * (slot & 3), kend);
-                reinterpret_cast<float4*>(img + (size_t)(1 + t) * 16 * KP)[slot] = vb;
+                float* imgB = img + (size_t)(1 + t) * 16 * KP;
+                if (dmaB) {
+                    const float* g = B_K4 ? Bv.addr(n0 + 16 * t + (slot & 15), kb + 4 * (slot >> 4), kend)
+                                          : Bv.addr(kb + (slot >> 2), n0 + 16 * t + 4 * (slot & 3), kend);
+                    glds16(g, imgB + pc * 256);
+                } else {
+                    float4 vb;
+                    if (B_K4) vb = Bv.get(n0 + 16 * t + (slot & 15), kb + 4 * (slot >> 4), kend);
+                    else      vb = Bv.get(kb + (slot >> 2), n0 + 16 * t + 4 * (slot & 3), kend);
+                    reinterpret_cast<float4*>(imgB)[slot] = vb;
+                }
             }
         }
-        __syncthreads();
-        const int ksteps = (klen + 3) >> 2;
-        for (int s = 0; s < ksteps; ++s) {
-            const float a = img[s * 64 + fragA];
+        const bool counted = dmaA && dmaB;  // pure LDS-DMA staging: release piece by piece
+        if (!counted) vm_wait(0);
+        // ---- contract: one piece = 4 MFMA k-steps per accumulator; out-of-range k was staged as zeros.
+        // The staged data is wave-private, so no workgroup barrier is needed here.
+        for (int pc = 0; pc < pieces; ++pc) {
+            if (counted) vm_wait((pieces - 1 - pc) * (NT + 1));
+            float a[4], b[NT][4];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const float b = img[(size_t)(1 + t) * 16 * KP + s * 64 + fragB];
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+            for (int s = 0; s < 4; ++s) {
+                a[s] = img[(pc * 4 + s) * 64 + fragA];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) b[t][s] = img[(size_t)(1 + t) * 16 * KP + (pc * 4 + s) * 64 + fragB];
             }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[t][s], acc[t], 0, 0, 0);
         }
-        __syncthreads();
     }
 
     // partial strips -> LDS (each wave reuses the head of its own staging region), row-major
@@ -225,9 +299,9 @@ __device__ __forceinline__ StripOut strip_mma(const AView& A, const BView& Bv, i
 // Speed-only remap of blockIdx -> (m strip, n strip): workgroups that read the same B panel
 // (same n strip) are dealt to the same XCD (blocks b and b+8 share one), so that each XCD's L2
 // holds 1/8 of the B operand.  Falls back to the plain map when nN is not a multiple of 8.
-__device__ __forceinline__ void strip_coords(int nM, int nN, int& ms, int& ns)
+__device__ __forceinline__ void strip_coords(int nM, int nN, int& ms, int& ns, int first = 0)
 {
-    const int id = blockIdx.x;
+    const int id = (int)blockIdx.x - first;  // `first` aux workgroups precede the strips in the grid
     if ((nN & 7) == 0) {
         const int x = id & 7, j = id >> 3;
         ns = x + 8 * (j / nM);

@@ -164,7 +164,7 @@ class HipRbmOps:
         B = A0.shape[0]
         gs = G.struct()
         check(self.lib.qbm_rbm_two_phase_grad(V, H, Cn, B, ptr(A0), ptr(Y0), ptr(P0), ptr(A1), ptr(Y1), ptr(P1),
-                                              C.byref(gs), None, 0.0, 0.0, 1.0, current_stream()),
+                                              C.byref(gs), None, None, 0.0, 0.0, 1.0, 0.0, current_stream()),
               "qbm_rbm_two_phase_grad")
 
     # ---- test hooks ---------------------------------------------------------------------------
