@@ -64,7 +64,7 @@ def main():
 
     from qbm_image_classification_amd import _lib
     from qbm_image_classification_amd.rbm_ops import GradSet, HipRbmOps, ParamSet
-    from qbm_image_classification_amd._lib import CdWorkspace, check, ptr
+    from qbm_image_classification_amd._lib import QBM_U8, CdWorkspace, check, ptr
 
     ops = HipRbmOps(str(dev))
     lib = ops.lib
@@ -82,7 +82,7 @@ def main():
     data_v, data_y = [], []
     for i in range(NB):
         u = ops.uniform(1234, i, row_base, B, V)
-        data_v.append((u < 0.5).float().contiguous())
+        data_v.append((u < 0.5).to(torch.uint8).contiguous())   # binary visibles held as uint8 {0,1}
         ul = ops.uniform(4321, i, row_base, B, 1).view(-1)
         lab = torch.clamp((ul * NC).long(), max=NC - 1)
         data_y.append(torch.nn.functional.one_hot(lab, NC).float().contiguous())
@@ -96,11 +96,11 @@ def main():
         j = i % NB
         off = 4 * i
         if world == 1:
-            check(lib.qbm_rbm_cd_step(C.byref(ps), C.byref(gs), ptr(data_v[j]), ptr(data_y[j]), B, K_CD, 42, off,
+            check(lib.qbm_rbm_cd_step(C.byref(ps), C.byref(gs), ptr(data_v[j]), QBM_U8, ptr(data_y[j]), B, K_CD, 42, off,
                                       row_base, None, None, C.byref(cws), 1, lr, factor, global_B, sparse, stream),
                   "qbm_rbm_cd_step")
         else:
-            check(lib.qbm_rbm_cd_step(C.byref(ps), C.byref(gs), ptr(data_v[j]), ptr(data_y[j]), B, K_CD, 42, off,
+            check(lib.qbm_rbm_cd_step(C.byref(ps), C.byref(gs), ptr(data_v[j]), QBM_U8, ptr(data_y[j]), B, K_CD, 42, off,
                                       row_base, None, None, C.byref(cws), 0, lr, factor, global_B, sparse, stream),
                   "qbm_rbm_cd_step")
             dist.all_reduce(G.flat, op=dist.ReduceOp.SUM)          # RCCL over xGMI, one collective per step
@@ -175,13 +175,13 @@ def main():
         kernels = {
             # name: (launcher, algorithmic FLOPs per launch, launches per CD-1 step)
             "k_hidden (sample_hidden, x2 per step)": (
-                lambda s: lib.qbm_rbm_sample_hidden(C.byref(ps), ptr(v0), ptr(y0), B, ptr(ph0), ptr(h), 42, 0, 0, s),
+                lambda s: lib.qbm_rbm_sample_hidden_ex(C.byref(ps), ptr(v0), QBM_U8, ptr(y0), B, ptr(ph0), None, ptr(h), 42, 0, 0, s),
                 2.0 * B * V * H + 2.0 * B * NC * H, 2),
-            "k_visible (sample_visible)": (
-                lambda s: lib.qbm_rbm_sample_visible(C.byref(ps), ptr(h), B, None, ptr(vk), 42, 1, 0, s),
+            "k_visible (sample_visible + class conditional)": (
+                lambda s: lib.qbm_rbm_sample_visible_class_ex(C.byref(ps), ptr(h), QBM_U8, B, None, None, ptr(vk), None, ptr(yk), 42, 1, 2, 0, s),
                 2.0 * B * V * H, 1),
             "k_grad (two-phase gradient + fused W update)": (
-                lambda s: lib.qbm_rbm_two_phase_grad(V, H, NC, B, ptr(v0), ptr(y0), ptr(ph0), ptr(vk), ptr(yk), ptr(phk),
+                lambda s: lib.qbm_rbm_two_phase_grad(V, H, NC, B, ptr(v0), QBM_U8, ptr(y0), ptr(ph0), ptr(vk), QBM_U8, ptr(yk), ptr(phk),
                                                      C.byref(ng), ptr(scratchW), None, lr, factor, global_B, sparse, s),
                 4.0 * B * V * H + 4.0 * B * NC * H, 1),
         }

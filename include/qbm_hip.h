@@ -29,9 +29,14 @@
 extern "C" {
 #endif
 
-#define QBM_ABI_VERSION 1
-#define QBM_MAX_CLASSES 32
+#define QBM_ABI_VERSION 2
+#define QBM_MAX_CLASSES 31 /* class rows + the bias row share one 32-row gradient strip */
 #define QBM_MAX_QUBO_VARS 1024
+
+/* element type of a Gibbs-state tensor: fp32 (what the reference holds) or uint8 {0,1} (exact for
+ * binary states and 4x less L2 -> LDS staging traffic, the resource that bounds these kernels) */
+#define QBM_F32 0
+#define QBM_U8 1
 
 #define QBM_OK 0
 #define QBM_ERR_ARG (-1) /* bad dimension / null pointer */
@@ -76,6 +81,12 @@ QBM_API int qbm_rbm_sample_hidden(const qbm_rbm_params* P, const float* v, const
                                   float* p_h, float* h_sample, uint64_t seed, uint64_t offset, uint32_t row0,
                                   void* stream);
 
+/* The same with a typed input and typed sample outputs: v is fp32 or uint8 (v_dtype), the sample can be
+ * written as fp32 (h_f32) and/or uint8 (h_u8). */
+QBM_API int qbm_rbm_sample_hidden_ex(const qbm_rbm_params* P, const void* v, int v_dtype, const float* y1hot, int B,
+                                     float* p_h, float* h_f32, uint8_t* h_u8, uint64_t seed, uint64_t offset,
+                                     uint32_t row0, void* stream);
+
 /* x.W + d, the `precomputed_factor` of src/ClassificationRBM.py:65 and :106.  pre[B,H]. */
 QBM_API int qbm_rbm_hidden_preact(const qbm_rbm_params* P, const float* x, int B, float* pre, void* stream);
 
@@ -84,10 +95,11 @@ QBM_API int qbm_rbm_sample_visible(const qbm_rbm_params* P, const float* h, int 
                                    uint64_t seed, uint64_t offset, uint32_t row0, void* stream);
 
 /* sample_visible and sample_class of the same hidden state in ONE launch (the class conditional rides
- * along as extra workgroups): what a Gibbs step h -> (v, y) needs. */
-QBM_API int qbm_rbm_sample_visible_class(const qbm_rbm_params* P, const float* h, int B, float* p_v,
-                                         float* v_sample, float* p_y, float* y1hot, uint64_t seed,
-                                         uint64_t offset_v, uint64_t offset_y, uint32_t row0, void* stream);
+ * along as extra workgroups): what a Gibbs step h -> (v, y) needs.  h is fp32 or uint8;
+ * p_y / y1hot both NULL = visible units only. */
+QBM_API int qbm_rbm_sample_visible_class_ex(const qbm_rbm_params* P, const void* h, int h_dtype, int B, float* p_v,
+                                            float* v_f32, uint8_t* v_u8, float* p_y, float* y1hot, uint64_t seed,
+                                            uint64_t offset_v, uint64_t offset_y, uint32_t row0, void* stream);
 
 /* ClassificationRBM.sample_class, src/ClassificationRBM.py:54-60: exp(h.U^T + c), L1-normalised.
  * p_y[B,C] and/or a categorical one-hot draw y1hot[B,C]. */
@@ -116,14 +128,15 @@ QBM_API int qbm_rbm_disc_class_grad(const qbm_rbm_params* P, const float* pre, c
 /* Two-phase batch gradient (CD-k: SURVEY.md 8.A-7; discriminative: src/ClassificationRBM.py:118-138):
  *   gW = A0^T.P0 - A1^T.P1,  gU = Y0^T.P0 - Y1^T.P1,  gd = colsum(P0) - colsum(P1),
  *   gb = colsum(A0) - colsum(A1),  gc = colsum(Y0) - colsum(Y1)
- * A*[B,V], Y*[B,C] (NULL = zeros), P*[B,H].  Outputs as selected by the non-NULL fields of G.
+ * A*[B,V] fp32 or uint8 (a*_dtype), Y*[B,C] (NULL = zeros), P*[B,H].  Outputs as selected by the
+ * non-NULL fields of G.
  * W_fused non-NULL: additionally W += factor*gW*lr/batch_size in the same pass
  * (src/ClassificationRBM.py:90); gW itself may then be NULL.  aux_fused non-NULL: its b, d, U, c blocks
  * are updated in the same launch as well (:91-99, including the sparse_constant subtraction). */
-QBM_API int qbm_rbm_two_phase_grad(int V, int H, int C, int B, const float* A0, const float* Y0, const float* P0,
-                                   const float* A1, const float* Y1, const float* P1, const qbm_rbm_grads* G,
-                                   float* W_fused, const qbm_rbm_params* aux_fused, float lr, float factor,
-                                   float batch_size, float sparse_constant, void* stream);
+QBM_API int qbm_rbm_two_phase_grad(int V, int H, int C, int B, const void* A0, int a0_dtype, const float* Y0,
+                                   const float* P0, const void* A1, int a1_dtype, const float* Y1, const float* P1,
+                                   const qbm_rbm_grads* G, float* W_fused, const qbm_rbm_params* aux_fused, float lr,
+                                   float factor, float batch_size, float sparse_constant, void* stream);
 
 /* ClassificationRBM.update_weights, src/ClassificationRBM.py:88-99:
  * theta += factor*grad*lr/batch_size; b, d, c -= sparse_constant.  G->gW == NULL skips W (already
@@ -133,30 +146,34 @@ QBM_API int qbm_rbm_update(const qbm_rbm_params* P, const qbm_rbm_grads* G, floa
 
 /* ---- composites: launch sequences on `stream` (graph-capturable) ---------------------------- */
 
-/* caller-owned scratch of one CD-k / PCD step */
+/* fp32 -> uint8 conversion of a {0,1} tensor (n elements), for callers that hold binary data as floats */
+QBM_API int qbm_f32_to_u8(const float* x, uint8_t* y, long n, void* stream);
+
+/* caller-owned scratch of one CD-k / PCD step; the Gibbs states are uint8 {0,1} */
 typedef struct {
     float* ph0;   /* [B,H] positive-phase hidden probabilities */
-    float* h;     /* [B,H] current hidden sample */
-    float* vk;    /* [B,V] */
-    float* yk;    /* [B,C] */
+    uint8_t* h;   /* [B,H] current hidden sample */
+    uint8_t* vk;  /* [B,V] */
+    float* yk;    /* [B,C] one-hot */
     float* phk;   /* [B,H] */
 } qbm_rbm_cd_workspace;
 
 /* k-step block-Gibbs chain (declared, never implemented in the reference:
- * src/ClassificationRBM.py:19, :179-182).  Draw ids: h_0 -> offset; t = 1..k: v_t -> offset+3t-2,
- * y_t -> offset+3t-1, h_t -> offset+3t.  chain_v/chain_y non-NULL = persistent chains (PCD): the
- * negative chain starts from them and they receive (v_k, y_k). */
-QBM_API int qbm_rbm_cd_chain(const qbm_rbm_params* P, const float* v0, const float* y0, int B, int k,
-                             uint64_t seed, uint64_t offset, uint32_t row0, float* chain_v, float* chain_y,
+ * src/ClassificationRBM.py:19, :179-182).  v0[B,V] fp32 or uint8 (v0_dtype), y0[B,C] fp32.
+ * Draw ids: h_0 -> offset; t = 1..k: v_t -> offset+3t-2, y_t -> offset+3t-1, h_t -> offset+3t.
+ * chain_v (uint8 [B,V]) / chain_y (fp32 [B,C]) non-NULL = persistent chains (PCD): the negative chain
+ * starts from them and they receive (v_k, y_k). */
+QBM_API int qbm_rbm_cd_chain(const qbm_rbm_params* P, const void* v0, int v0_dtype, const float* y0, int B, int k,
+                             uint64_t seed, uint64_t offset, uint32_t row0, uint8_t* chain_v, float* chain_y,
                              const qbm_rbm_cd_workspace* ws, void* stream);
 
-/* chain + gradient (+ update).  G: gradient blocks (data-parallel path: all-reduce them, then call
- * qbm_rbm_update).  fuse_update != 0: single-GPU path, W is updated inside the gradient pass and the
- * remaining blocks by one update launch; G must still provide gb, gd, gU, gc. */
-QBM_API int qbm_rbm_cd_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const float* v0, const float* y0,
-                            int B, int k, uint64_t seed, uint64_t offset, uint32_t row0, float* chain_v,
-                            float* chain_y, const qbm_rbm_cd_workspace* ws, int fuse_update, float lr,
-                            float factor, float batch_size, float sparse_constant, void* stream);
+/* chain + gradient (+ update).  fuse_update == 0: the gradients go to G (all five blocks required; the
+ * data-parallel path all-reduces them, then calls qbm_rbm_update).  fuse_update != 0: single-GPU path, every
+ * parameter block is updated inside the gradient launch (the non-NULL blocks of G are still written). */
+QBM_API int qbm_rbm_cd_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void* v0, int v0_dtype,
+                            const float* y0, int B, int k, uint64_t seed, uint64_t offset, uint32_t row0,
+                            uint8_t* chain_v, float* chain_y, const qbm_rbm_cd_workspace* ws, int fuse_update,
+                            float lr, float factor, float batch_size, float sparse_constant, void* stream);
 
 /* caller-owned scratch of one discriminative step */
 typedef struct {

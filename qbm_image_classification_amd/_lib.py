@@ -8,8 +8,9 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libqbm_hip.so")
 
-QBM_ABI_VERSION = 1
-QBM_MAX_CLASSES = 32
+QBM_ABI_VERSION = 2
+QBM_MAX_CLASSES = 31
+QBM_F32, QBM_U8 = 0, 1
 
 
 class QbmHipError(RuntimeError):
@@ -46,18 +47,20 @@ SIGNATURES = {
     "qbm_abi_version": [],
     "qbm_last_error": [],
     "qbm_rbm_sample_hidden": [_PP, _p, _p, _i, _p, _p, _u64, _u64, _u32, _p],
+    "qbm_rbm_sample_hidden_ex": [_PP, _p, _i, _p, _i, _p, _p, _p, _u64, _u64, _u32, _p],
     "qbm_rbm_hidden_preact": [_PP, _p, _i, _p, _p],
     "qbm_rbm_sample_visible": [_PP, _p, _i, _p, _p, _u64, _u64, _u32, _p],
     "qbm_rbm_sample_class": [_PP, _p, _i, _p, _p, _u64, _u64, _u32, _p],
     "qbm_rbm_free_energy": [_PP, _p, _i, _p, _p, _p, _p],
     "qbm_rbm_disc_terms": [_PP, _p, _p, _p, _i, _p, _p, _p, _p],
     "qbm_rbm_disc_class_grad": [_PP, _p, _p, _p, _i, _p, _p, _p],
-    "qbm_rbm_two_phase_grad": [_i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _GP, _p, _PP, _f, _f, _f, _f, _p],
-    "qbm_rbm_sample_visible_class": [_PP, _p, _i, _p, _p, _p, _p, _u64, _u64, _u64, _u32, _p],
+    "qbm_rbm_two_phase_grad": [_i, _i, _i, _i, _p, _i, _p, _p, _p, _i, _p, _p, _GP, _p, _PP, _f, _f, _f, _f, _p],
+    "qbm_rbm_sample_visible_class_ex": [_PP, _p, _i, _i, _p, _p, _p, _p, _p, _u64, _u64, _u64, _u32, _p],
+    "qbm_f32_to_u8": [_p, _p, C.c_long, _p],
     "qbm_rbm_update": [_PP, _GP, _f, _f, _f, _f, _p],
-    "qbm_rbm_cd_chain": [_PP, _p, _p, _i, _i, _u64, _u64, _u32, _p, _p, C.POINTER(CdWorkspace), _p],
-    "qbm_rbm_cd_step": [_PP, _GP, _p, _p, _i, _i, _u64, _u64, _u32, _p, _p, C.POINTER(CdWorkspace), _i, _f, _f, _f,
-                        _f, _p],
+    "qbm_rbm_cd_chain": [_PP, _p, _i, _p, _i, _i, _u64, _u64, _u32, _p, _p, C.POINTER(CdWorkspace), _p],
+    "qbm_rbm_cd_step": [_PP, _GP, _p, _i, _p, _i, _i, _u64, _u64, _u32, _p, _p, C.POINTER(CdWorkspace), _i, _f, _f,
+                        _f, _f, _p],
     "qbm_rbm_disc_step": [_PP, _GP, _p, _p, _i, _p, _p, C.POINTER(DiscWorkspace), _i, _i, _f, _f, _f, _f, _p],
     "qbm_test_math": [_i, _p, _p, _i, _p],
     "qbm_test_uniform": [_u64, _u64, _u32, _i, _i, _p, _p],

@@ -174,7 +174,7 @@ class ClassificationRBM:
         row0 = (self._rows_seen + rank_rows) & 0xFFFFFFFF
         offset = self._next_offset(3 * self.k + 1)
         if self.persistent and (self._chain_v is None or self._chain_v.shape[0] != batch_size):
-            self._chain_v = v0.clone()
+            self._chain_v = self.ops.to_u8(v0)      # chains start at the data (binary states, uint8)
             self._chain_y = y0.clone()
         cv = self._chain_v if self.persistent else None
         cy = self._chain_y if self.persistent else None

@@ -117,7 +117,7 @@ __device__ __forceinline__ float wave_butterfly_sum(float p)
     return p;
 }
 
-// [Q] length of one K quarter: roundup4(ceil(K / 4))
-__host__ __device__ __forceinline__ int quarter_len(int K) { return (((K + 3) / 4) + 3) / 4 * 4; }
+// [Q] length of one K quarter: roundup16(ceil(K / 4)) -- a whole number of 16-k staging pieces
+__host__ __device__ __forceinline__ int quarter_len(int K) { return (((K + 3) / 4) + 15) / 16 * 16; }
 
 }  // namespace qbm

@@ -24,6 +24,8 @@ int hip_fail(hipError_t e, const char* where)
 
 namespace {
 
+constexpr int MT = 2, NT = 1;  // every strip is 32 rows x 16 columns: two row tiles share each staged B fragment
+
 // class-count buckets for the kernels that keep one register (or one float4) per class
 #define QBM_DISPATCH_CM(C, MACRO)                   \
     do {                                            \
@@ -33,36 +35,51 @@ namespace {
         else { MACRO(QBM_MAX_CLASSES); }            \
     } while (0)
 
+template <class T> struct KView;   // K-contiguous A operand of element type T
+template <> struct KView<float> { using type = ViewKContig; };
+template <> struct KView<uint8_t> { using type = ViewKContigU8; };
+template <class T> struct CView;   // M-contiguous A operand of element type T
+template <> struct CView<float> { using type = ViewCContig; };
+template <> struct CView<uint8_t> { using type = ViewCContigU8; };
+
+template <class T>
+__device__ __forceinline__ float ld_state(const void* p, long i)
+{
+    return (float)reinterpret_cast<const T*>(p)[i];
+}
+
 // ---------------------------------------------------------------------------------------------
 // A-1  sample_hidden  (src/ClassificationRBM.py:43-47):  p = sigma(v.W + d + y.U);  h = (p > u)
 // MODE 0: probabilities (+ optional sample);  MODE 1: pre-activation v.W + d only (:65, :106).
+// TA: element type of v (float, or uint8 for {0,1} Gibbs states).
 // ---------------------------------------------------------------------------------------------
 struct HiddenArgs {
-    const float* v;  // [B,V]
+    const void* v;   // [B,V] TA
     const float* y;  // [B,C] or null
     const float* W;  // [V,H]
     const float* d;  // [H]
     const float* U;  // [C,H]
     float* p;        // [B,H] or null
-    float* s;        // [B,H] or null
+    float* s;        // [B,H] or null   sample as fp32 {0,1}
+    uint8_t* s8;     // [B,H] or null   sample as uint8 {0,1}
     int B, V, H, C;
     int KP;
     uint64_t seed, offset;
     uint32_t row0;
-    bool vecA, vecB, vecO;
+    bool vecO;
 };
 
-template <int NT, int MODE, int CM>
+template <class TA, bool FAST, int MODE, int CM>
 __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int nM = (a.B + 15) / 16, nN = (a.H + 16 * NT - 1) / (16 * NT);
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int nM = (a.B + 16 * MT - 1) / (16 * MT), nN = (a.H + 16 * NT - 1) / (16 * NT);
     int ms, ns;
     strip_coords(nM, nN, ms, ns);
-    const int m0 = ms * 16, n0 = ns * 16 * NT;
-    const ViewKContig A{a.v, a.V, a.B, a.vecA};
-    const ViewCContig Bv{a.W, a.H, a.H, a.vecB};
-    const StripOut o = strip_mma<NT, true, false>(A, Bv, m0, n0, a.V, lds, a.KP);
+    const int m0 = ms * 16 * MT, n0 = ns * 16 * NT;
+    const typename KView<TA>::type A{reinterpret_cast<const TA*>(a.v), a.V, a.B};
+    const ViewCContig Bv{a.W, a.H, a.H, a.V};
+    const StripOut o = strip_mma<MT, NT, FAST>(A, Bv, m0, n0, a.V, lds, a.KP);
     if (!o.valid) return;
     const int i = m0 + o.row, j0 = n0 + 4 * o.cg;
     if (i >= a.B || j0 >= a.H) return;
@@ -106,7 +123,7 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
     }
     float pv[4], hv[4];
     f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (MODE == 0 && a.s) u = uniform4(a.seed, a.offset, a.row0 + (uint32_t)i, (uint32_t)(j0 >> 2));
+    if (MODE == 0 && (a.s || a.s8)) u = uniform4(a.seed, a.offset, a.row0 + (uint32_t)i, (uint32_t)(j0 >> 2));
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         float x = sv[e] + dv[e];
@@ -122,10 +139,13 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
     if (vec) {
         if (a.p) *reinterpret_cast<float4*>(a.p + off) = make_float4(pv[0], pv[1], pv[2], pv[3]);
         if (MODE == 0 && a.s) *reinterpret_cast<float4*>(a.s + off) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+        if (MODE == 0 && a.s8)
+            *reinterpret_cast<uint32_t*>(a.s8 + off) = (uint32_t)hv[0] | ((uint32_t)hv[1] << 8) | ((uint32_t)hv[2] << 16) | ((uint32_t)hv[3] << 24);
     } else {
         for (int e = 0; e < 4 && j0 + e < a.H; ++e) {
             if (a.p) a.p[off + e] = pv[e];
             if (MODE == 0 && a.s) a.s[off + e] = hv[e];
+            if (MODE == 0 && a.s8) a.s8[off + e] = (uint8_t)hv[e];
         }
     }
 }
@@ -135,8 +155,8 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
 // categorical draw: one uniform per row, first class whose running sum exceeds u.
 // One wavefront per row; the sum over j is the wave tree [T].  All loads are unconditional.
 // ---------------------------------------------------------------------------------------------
-template <int CM>
-__device__ __forceinline__ void class_row(const float* __restrict__ h, const float* __restrict__ U,
+template <class TH, int CM>
+__device__ __forceinline__ void class_row(const void* __restrict__ h, const float* __restrict__ U,
                                           const float* __restrict__ cb, float* __restrict__ p_out,
                                           float* __restrict__ y_out, int i, int H, int C, uint64_t seed,
                                           uint64_t offset, uint32_t row0, int lane)
@@ -152,7 +172,7 @@ __device__ __forceinline__ void class_row(const float* __restrict__ h, const flo
         for (int t = 0; t < 4; ++t) {
             const int j = jb + t * kWave + lane;
             const int jj = min(j, H - 1);
-            const float x = h[(long)i * H + jj];
+            const float x = ld_state<TH>(h, (long)i * H + jj);
             hv[t] = (j < H) ? x : 0.f;
 #pragma unroll
             for (int c = 0; c < CM; ++c) uv[t][c] = U[(long)min(c, C - 1) * H + jj];
@@ -187,58 +207,59 @@ __device__ __forceinline__ void class_row(const float* __restrict__ h, const flo
         for (int c = 0; c < C; ++c) y_out[(long)i * C + c] = (c == pick) ? 1.f : 0.f;
 }
 
-template <int CM>
-__global__ __launch_bounds__(256) void k_class(const float* __restrict__ h, const float* __restrict__ U,
+template <class TH, int CM>
+__global__ __launch_bounds__(256) void k_class(const void* __restrict__ h, const float* __restrict__ U,
                                                const float* __restrict__ cb, float* __restrict__ p_out,
                                                float* __restrict__ y_out, int B, int H, int C, uint64_t seed,
                                                uint64_t offset, uint32_t row0)
 {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i < B) class_row<CM>(h, U, cb, p_out, y_out, i, H, C, seed, offset, row0, threadIdx.x & 63);
+    if (i < B) class_row<TH, CM>(h, U, cb, p_out, y_out, i, H, C, seed, offset, row0, threadIdx.x & 63);
 }
 
 // ---------------------------------------------------------------------------------------------
 // A-2  sample_visible  (src/ClassificationRBM.py:49-52):  p = sigma(h.W^T + b);  v = (p > u)
 // W is read as stored ([V,H], H contiguous): it is the K-contiguous B operand.
 // The launch can carry the class conditional of the same hidden state (A-3) as extra workgroups
-// appended to the grid ("aux" workgroups, 16 rows each): both read h only, so one launch serves both
-// and the tiny class product hides behind the strips.
+// placed first in the grid (8 rows each): both read h only, so one launch serves both and the tiny
+// class product hides behind the strips.
 // ---------------------------------------------------------------------------------------------
 struct VisibleArgs {
-    const float* h;  // [B,H]
+    const void* h;   // [B,H] TA
     const float* W;  // [V,H]
     const float* b;  // [V]
     float* p;        // [B,V] or null
-    float* s;        // [B,V] or null
+    float* s;        // [B,V] or null  fp32 {0,1}
+    uint8_t* s8;     // [B,V] or null  uint8 {0,1}
     int B, V, H;
     int KP;
     uint64_t seed, offset;
     uint32_t row0;
-    bool vecA, vecB, vecO;
+    bool vecO;
     // class conditional riding along (all null/0 when not wanted)
     const float* U; const float* cb; float* py; float* ys;
     int C; uint64_t offset_y;
     int n_aux;  // aux workgroups come first in the grid
 };
 
-template <int NT, int CM>
+template <class TA, bool FAST, int CM>
 __global__ __launch_bounds__(256) void k_visible(VisibleArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    extern __shared__ __attribute__((aligned(16))) char lds[];
     if ((int)blockIdx.x < a.n_aux) {  // aux workgroup (dealt first): class conditional, 8 rows, 2 per wave
         const int base = (int)blockIdx.x * 8 + (threadIdx.x >> 6) * 2;
         for (int r = 0; r < 2; ++r)
             if (base + r < a.B)
-                class_row<CM>(a.h, a.U, a.cb, a.py, a.ys, base + r, a.H, a.C, a.seed, a.offset_y, a.row0, threadIdx.x & 63);
+                class_row<TA, CM>(a.h, a.U, a.cb, a.py, a.ys, base + r, a.H, a.C, a.seed, a.offset_y, a.row0, threadIdx.x & 63);
         return;
     }
-    const int nM = (a.B + 15) / 16, nN = (a.V + 16 * NT - 1) / (16 * NT);
+    const int nM = (a.B + 16 * MT - 1) / (16 * MT), nN = (a.V + 16 * NT - 1) / (16 * NT);
     int ms, ns;
     strip_coords(nM, nN, ms, ns, a.n_aux);
-    const int m0 = ms * 16, n0 = ns * 16 * NT;
-    const ViewKContig A{a.h, a.H, a.B, a.vecA};
-    const ViewKContig Bv{a.W, a.H, a.V, a.vecB};
-    const StripOut o = strip_mma<NT, true, true>(A, Bv, m0, n0, a.H, lds, a.KP);
+    const int m0 = ms * 16 * MT, n0 = ns * 16 * NT;
+    const typename KView<TA>::type A{reinterpret_cast<const TA*>(a.h), a.H, a.B};
+    const ViewKContig Bv{a.W, a.H, a.V};
+    const StripOut o = strip_mma<MT, NT, FAST>(A, Bv, m0, n0, a.H, lds, a.KP);
     if (!o.valid) return;
     const int i = m0 + o.row, k0 = n0 + 4 * o.cg;
     if (i >= a.B || k0 >= a.V) return;
@@ -254,7 +275,7 @@ __global__ __launch_bounds__(256) void k_visible(VisibleArgs a)
     }
     float pv[4], vv[4];
     f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (a.s) u = uniform4(a.seed, a.offset, a.row0 + (uint32_t)i, (uint32_t)(k0 >> 2));
+    if (a.s || a.s8) u = uniform4(a.seed, a.offset, a.row0 + (uint32_t)i, (uint32_t)(k0 >> 2));
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         pv[e] = det_sigmoid(sv[e] + bv[e]);
@@ -264,10 +285,13 @@ __global__ __launch_bounds__(256) void k_visible(VisibleArgs a)
     if (vec) {
         if (a.p) *reinterpret_cast<float4*>(a.p + off) = make_float4(pv[0], pv[1], pv[2], pv[3]);
         if (a.s) *reinterpret_cast<float4*>(a.s + off) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        if (a.s8)
+            *reinterpret_cast<uint32_t*>(a.s8 + off) = (uint32_t)vv[0] | ((uint32_t)vv[1] << 8) | ((uint32_t)vv[2] << 16) | ((uint32_t)vv[3] << 24);
     } else {
         for (int e = 0; e < 4 && k0 + e < a.V; ++e) {
             if (a.p) a.p[off + e] = pv[e];
             if (a.s) a.s[off + e] = vv[e];
+            if (a.s8) a.s8[off + e] = (uint8_t)vv[e];
         }
     }
 }
@@ -374,27 +398,41 @@ __global__ __launch_bounds__(256) void k_disc_class_grad(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
-// A-5 / A-7 gradient (reference association sums: src/ClassificationRBM.py:118-138):
-//   gW = A0^T.P0 - A1^T.P1                                   strip workgroups (MFMA), grid part 1
-//   gU = Y0^T.P0 - Y1^T.P1, gd = colsum P0 - colsum P1        aux workgroups "H": 64 hidden columns each
-//   gb = colsum A0 - colsum A1                                aux workgroups "V": 64 visible columns each
-//   gc = colsum Y0 - colsum Y1                                aux workgroup  "C"
-// Every contraction over the batch is the quartered chain [Q]: in the aux workgroups wave q walks
-// batch quarter q with plain fmaf chains (lane = column), the four partials meet in LDS.
-// Optional fused A-6 update (src/ClassificationRBM.py:88-99): W in the strip epilogue, b/d/U/c in the
-// aux workgroups (single-GPU path; the data-parallel path all-reduces the gradients first).
+// A-5 / A-7 gradient (reference association sums: src/ClassificationRBM.py:118-138).
+// Every block of the gradient is a two-phase strip contraction over the batch (quartered chain [Q]):
+//   kind W : gW = A0^T.P0 - A1^T.P1                    A = data[b][m] (lin image; fp32 or u8), B = P
+//   kind U : [gU; gd] = [Y0 | 1]^T.P0 - [Y1 | 1]^T.P1   A = ViewAugY (class rows + a row of ones), B = P
+//   kind B : gb = A0^T.1 - A1^T.1                       A = data, B = a column of ones
+//   kind C : gc = 1^T.Y0 - 1^T.Y1                       A = a row of ones, B = Y
+// The few U/B/C workgroups come first in the grid.  Optional fused A-6 update
+// (src/ClassificationRBM.py:88-99) in the epilogue of each kind (single-GPU path; the data-parallel
+// path all-reduces the gradients first).
 // ---------------------------------------------------------------------------------------------
+
+// B operand with a single column of ones (column sums of the A operand land in output column 0)
+struct ViewOnesCol {
+    using elem = float;
+    static constexpr bool kK4 = false;
+    __device__ __forceinline__ rsrc_t rsrc() const { return make_rsrc(nullptr, 0); }
+    __device__ __forceinline__ DmaLane lane0(int, int, int) const { return DmaLane{kOOB, 0u, 0, 0}; }
+    __device__ __forceinline__ float4 get(int c0, int kb, int kend, int slot) const
+    {
+        const int c = c0 + 4 * (slot & 3), k = kb + (slot >> 2);
+        return make_float4((k < kend && c == 0) ? 1.f : 0.f, 0.f, 0.f, 0.f);
+    }
+};
+
 struct GradArgs {
-    const float* A0; const float* Y0; const float* P0;
-    const float* A1; const float* Y1; const float* P1;
+    const void* A0; const float* Y0; const float* P0;
+    const void* A1; const float* Y1; const float* P1;
     float* gW; float* gb; float* gd; float* gU; float* gc;
-    float* W;                             // non-null: fused W update
-    float* ub; float* ud; float* uU; float* uc;  // non-null: fused update of b, d, U, c in the aux workgroups
+    float* W;                                    // non-null: fused W update
+    float* ub; float* ud; float* uU; float* uc;  // non-null: fused update of b, d, U, c
     float lr, factor, bs, sparse;
     int B, V, H, C;
     int KP;
-    int n_aux, n_auxH, n_auxV;            // grid = n_aux + strips; n_aux = n_auxH + n_auxV + (gc wanted ? 1 : 0)
-    bool vecA, vecP, vecO;
+    int nU, nB, nC;                              // workgroups of kind U, B, C (they precede kind W)
+    bool vecO;
 };
 
 __device__ __forceinline__ float upd(float th, float g, const GradArgs& a, bool sparse)
@@ -406,123 +444,72 @@ __device__ __forceinline__ float upd(float th, float g, const GradArgs& a, bool 
     return sparse ? th - a.sparse : th;
 }
 
-template <int CM>
-__device__ __forceinline__ void grad_aux(const GradArgs& a, float* lds)
-{
-    const int lane = threadIdx.x & 63;
-    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int Kq = quarter_len(a.B);
-    const int i0 = q * Kq, i1 = min(a.B, i0 + Kq);
-    int blk = (int)blockIdx.x;
-    constexpr int NACC = 2 * (CM + 1);
-    float acc[NACC];
-#pragma unroll
-    for (int t = 0; t < NACC; ++t) acc[t] = 0.f;
-    int kind, col;
-    if (blk < a.n_auxH) {          // 64 hidden columns: gd and gU[:, col]
-        kind = 0; col = blk * 64 + lane;
-        const int cc = min(col, a.H - 1);
-        // a null Y is read as zeros through stride 0 on the zero page: every load stays unconditional
-        const float* y0p = a.Y0 ? a.Y0 : g_zero16;
-        const float* y1p = a.Y1 ? a.Y1 : g_zero16;
-        const long ys0 = a.Y0 ? a.C : 0, ys1 = a.Y1 ? a.C : 0;
-        for (int ib = i0; ib < i1; ib += 64) {   // 64 batch rows per trip: lane l holds Y[ib + l, :]
-            const int ir = min(ib + lane, a.B - 1);
-            float y0r[CM], y1r[CM];
-#pragma unroll
-            for (int c = 0; c < CM; ++c) {
-                const int ci = min(c, a.C - 1);
-                y0r[c] = y0p[ir * ys0 + (a.Y0 ? ci : 0)];
-                y1r[c] = y1p[ir * ys1 + (a.Y1 ? ci : 0)];
-            }
-            const int cnt = min(64, i1 - ib);
-#pragma unroll 4
-            for (int l = 0; l < cnt; ++l) {
-                const float p0 = a.P0[(long)(ib + l) * a.H + cc], p1 = a.P1[(long)(ib + l) * a.H + cc];
-                acc[0] = __builtin_fmaf(1.0f, p0, acc[0]);
-                acc[1] = __builtin_fmaf(1.0f, p1, acc[1]);
-#pragma unroll
-                for (int c = 0; c < CM; ++c) {
-                    const float y0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y0r[c]), l));
-                    const float y1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y1r[c]), l));
-                    acc[2 + 2 * c] = __builtin_fmaf(y0, p0, acc[2 + 2 * c]);
-                    acc[3 + 2 * c] = __builtin_fmaf(y1, p1, acc[3 + 2 * c]);
-                }
-            }
-        }
-    } else if ((blk -= a.n_auxH) < a.n_auxV) {  // 64 visible columns: gb
-        kind = 1; col = blk * 64 + lane;
-        const int cc = min(col, a.V - 1);
-#pragma unroll 8
-        for (int i = i0; i < i1; ++i) {
-            acc[0] = __builtin_fmaf(a.A0[(long)i * a.V + cc], 1.0f, acc[0]);
-            acc[1] = __builtin_fmaf(a.A1[(long)i * a.V + cc], 1.0f, acc[1]);
-        }
-    } else {                        // class columns: gc
-        kind = 2; col = lane;
-        const int cc = min(col, a.C - 1);
-        const float* y0p = a.Y0 ? a.Y0 : g_zero16;
-        const float* y1p = a.Y1 ? a.Y1 : g_zero16;
-        const long ys0 = a.Y0 ? a.C : 0, ys1 = a.Y1 ? a.C : 0;
-        const int c0 = a.Y0 ? cc : 0, c1 = a.Y1 ? cc : 0;
-#pragma unroll 8
-        for (int i = i0; i < i1; ++i) {
-            acc[0] = __builtin_fmaf(y0p[i * ys0 + c0], 1.0f, acc[0]);
-            acc[1] = __builtin_fmaf(y1p[i * ys1 + c1], 1.0f, acc[1]);
-        }
-    }
-    // partials -> LDS [q][acc][lane]
-#pragma unroll
-    for (int t = 0; t < NACC; ++t) lds[(q * NACC + t) * 64 + lane] = acc[t];
-    __syncthreads();
-    if (q != 0) return;
-    float g[CM + 1];
-#pragma unroll
-    for (int t = 0; t < CM + 1; ++t) {
-        float s[2];
-#pragma unroll
-        for (int ph = 0; ph < 2; ++ph) {
-            const int idx = 2 * t + ph;
-            s[ph] = ((lds[(0 * NACC + idx) * 64 + lane] + lds[(1 * NACC + idx) * 64 + lane]) + lds[(2 * NACC + idx) * 64 + lane]) +
-                    lds[(3 * NACC + idx) * 64 + lane];
-        }
-        g[t] = s[0] - s[1];
-    }
-    if (kind == 0) {
-        if (col >= a.H) return;
-        if (a.gd) a.gd[col] = g[0];
-        if (a.ud) a.ud[col] = upd(a.ud[col], g[0], a, true);
-#pragma unroll
-        for (int c = 0; c < CM; ++c) {
-            if (c < a.C) {
-                if (a.gU) a.gU[(long)c * a.H + col] = g[1 + c];
-                if (a.uU) a.uU[(long)c * a.H + col] = upd(a.uU[(long)c * a.H + col], g[1 + c], a, false);
-            }
-        }
-    } else if (kind == 1) {
-        if (col >= a.V) return;
-        if (a.gb) a.gb[col] = g[0];
-        if (a.ub) a.ub[col] = upd(a.ub[col], g[0], a, true);
-    } else {
-        if (col >= a.C) return;
-        if (a.gc) a.gc[col] = g[0];
-        if (a.uc) a.uc[col] = upd(a.uc[col], g[0], a, true);
-    }
-}
-
-template <int NT, int CM>
+template <class T0, class T1, bool FAST>
 __global__ __launch_bounds__(256) void k_grad(GradArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    if ((int)blockIdx.x < a.n_aux) { grad_aux<CM>(a, lds); return; }  // aux workgroups are dealt first
-    const int nM = (a.V + 15) / 16, nN = (a.H + 16 * NT - 1) / (16 * NT);
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    int blk = blockIdx.x;
+    const ViewCContig P0{a.P0, a.H, a.H, a.B}, P1{a.P1, a.H, a.H, a.B};
+    const typename CView<T0>::type D0{reinterpret_cast<const T0*>(a.A0), a.V, a.V, a.B};
+    const typename CView<T1>::type D1{reinterpret_cast<const T1*>(a.A1), a.V, a.V, a.B};
+    if (blk < a.nU) {  // class-weight rows and the hidden-bias row (C + 1 <= 32 rows) x 16 hidden columns
+        const int n0 = blk * 16 * NT;
+        const ViewAugY Y0{a.Y0, a.C}, Y1{a.Y1, a.C};
+        const StripOut o0 = strip_mma<MT, NT, false>(Y0, P0, 0, n0, a.B, lds, a.KP);
+        const StripOut o1 = strip_mma<MT, NT, false>(Y1, P1, 0, n0, a.B, lds, a.KP);
+        if (!o0.valid || o0.row > a.C) return;
+        const float g[4] = {o0.sum.x - o1.sum.x, o0.sum.y - o1.sum.y, o0.sum.z - o1.sum.z, o0.sum.w - o1.sum.w};
+        for (int e = 0; e < 4; ++e) {
+            const int n = n0 + 4 * o0.cg + e;
+            if (n >= a.H) break;
+            if (o0.row < a.C) {
+                const long off = (long)o0.row * a.H + n;
+                if (a.gU) a.gU[off] = g[e];
+                if (a.uU) a.uU[off] = upd(a.uU[off], g[e], a, false);
+            } else {
+                if (a.gd) a.gd[n] = g[e];
+                if (a.ud) a.ud[n] = upd(a.ud[n], g[e], a, true);
+            }
+        }
+        return;
+    }
+    blk -= a.nU;
+    if (blk < a.nB) {  // visible bias: column sums of the data = data^T . ones, 32 visible units per workgroup
+        const int m0 = blk * 16 * MT;
+        const ViewOnesCol ones;
+        const StripOut o0 = strip_mma<MT, NT, false>(D0, ones, m0, 0, a.B, lds, a.KP);
+        const StripOut o1 = strip_mma<MT, NT, false>(D1, ones, m0, 0, a.B, lds, a.KP);
+        if (!o0.valid || o0.cg != 0) return;
+        const int m = m0 + o0.row;
+        if (m >= a.V) return;
+        const float g = o0.sum.x - o1.sum.x;
+        if (a.gb) a.gb[m] = g;
+        if (a.ub) a.ub[m] = upd(a.ub[m], g, a, true);
+        return;
+    }
+    blk -= a.nB;
+    if (blk < a.nC) {  // class bias: column sums of the labels = ones^T . Y, 16 classes per workgroup
+        const int n0 = blk * 16 * NT;
+        const ViewOnesRow ones;
+        const ViewCContig Y0{a.Y0, a.C, a.C, a.B}, Y1{a.Y1, a.C, a.C, a.B};
+        const StripOut o0 = strip_mma<MT, NT, false>(ones, Y0, 0, n0, a.B, lds, a.KP);
+        const StripOut o1 = strip_mma<MT, NT, false>(ones, Y1, 0, n0, a.B, lds, a.KP);
+        if (!o0.valid || o0.row != 0) return;
+        const float g[4] = {o0.sum.x - o1.sum.x, o0.sum.y - o1.sum.y, o0.sum.z - o1.sum.z, o0.sum.w - o1.sum.w};
+        for (int e = 0; e < 4; ++e) {
+            const int n = n0 + 4 * o0.cg + e;
+            if (n >= a.C) break;
+            if (a.gc) a.gc[n] = g[e];
+            if (a.uc) a.uc[n] = upd(a.uc[n], g[e], a, true);
+        }
+        return;
+    }
+    const int nM = (a.V + 16 * MT - 1) / (16 * MT), nN = (a.H + 16 * NT - 1) / (16 * NT);
     int ms, ns;
-    strip_coords(nM, nN, ms, ns, a.n_aux);
-    const int m0 = ms * 16, n0 = ns * 16 * NT;
-    const ViewCContig A0{a.A0, a.V, a.V, a.vecA}, A1{a.A1, a.V, a.V, a.vecA};
-    const ViewCContig B0{a.P0, a.H, a.H, a.vecP}, B1{a.P1, a.H, a.H, a.vecP};
-    const StripOut o0 = strip_mma<NT, false, false>(A0, B0, m0, n0, a.B, lds, a.KP);
-    const StripOut o1 = strip_mma<NT, false, false>(A1, B1, m0, n0, a.B, lds, a.KP);
+    strip_coords(nM, nN, ms, ns, a.nU + a.nB + a.nC);
+    const int m0 = ms * 16 * MT, n0 = ns * 16 * NT;
+    const StripOut o0 = strip_mma<MT, NT, FAST>(D0, P0, m0, n0, a.B, lds, a.KP);
+    const StripOut o1 = strip_mma<MT, NT, FAST>(D1, P1, m0, n0, a.B, lds, a.KP);
     if (!o0.valid) return;
     const int m = m0 + o0.row, nb = n0 + 4 * o0.cg;
     if (m >= a.V || nb >= a.H) return;
@@ -596,16 +583,20 @@ __global__ void k_uniform(uint64_t seed, uint64_t offset, uint32_t row0, int row
     for (int e = 0; e < 4 && 4 * cg + e < cols; ++e) out[(long)i * cols + 4 * cg + e] = u[e];
 }
 
+// fp32 {0,1} (or any value in 0..255) -> uint8, for callers that hold binary data as floats
+__global__ void k_f32_to_u8(const float* __restrict__ x, uint8_t* __restrict__ y, long n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = (uint8_t)x[i];
+}
+
 // ---- launch helpers ---------------------------------------------------------------------------
-template <int NT>
+template <int ASZ>
 int panel_for(int K)
 {
     const int Kq = quarter_len(K);
-    int KP = (Kq + 15) / 16 * 16;
-    // LDS-DMA staging keeps (NT+1) pieces per 16 k in flight and vm_wait counts to 60
-    int mx = strip_max_panel<NT>();
-    const int by_vmcnt = (60 / (NT + 1)) * 16;
-    if (by_vmcnt < mx) mx = by_vmcnt;
+    const int KP = (Kq + 63) / 64 * 64;
+    const int mx = strip_max_panel<MT, NT, ASZ>();
     return KP < mx ? KP : mx;
 }
 
@@ -629,89 +620,125 @@ int check_params(const qbm_rbm_params* P)
     return QBM_OK;
 }
 
-int launch_hidden(const qbm_rbm_params* P, const float* v, const float* y, int B, float* p, float* s, int mode,
-                  uint64_t seed, uint64_t offset, uint32_t row0, hipStream_t st)
+int check_dtype(int dt) { return (dt == QBM_F32 || dt == QBM_U8) ? QBM_OK : fail(QBM_ERR_ARG, "dtype must be QBM_F32 or QBM_U8"); }
+
+inline bool small2g(long elems, int esz) { return elems * esz < (1L << 31); }
+
+template <class TA>
+int launch_hidden_t(const qbm_rbm_params* P, const void* v, const float* y, int B, float* p, float* s, uint8_t* s8,
+                    int mode, uint64_t seed, uint64_t offset, uint32_t row0, hipStream_t st)
 {
-    constexpr int NT = 2;
-    HiddenArgs a{v, y, P->W, P->d, P->U, p, s, B, P->V, P->H, P->C, panel_for<NT>(P->V), seed, offset, row0,
-                 (P->V % 4 == 0) && aligned16(v), (P->H % 4 == 0) && aligned16(P->W),
-                 (P->H % 4 == 0) && (!p || aligned16(p)) && (!s || aligned16(s)) && aligned16(P->d) && aligned16(P->U)};
-    const int nM = (B + 15) / 16, nN = (P->H + 16 * NT - 1) / (16 * NT);
-    const size_t lds = sizeof(float) * strip_lds_floats<NT>(a.KP);
-    if (mode != 0 || !y) {  // no class term: the class-count bucket is irrelevant
-        if (mode == 0) {
-            if (int rc = set_lds(k_hidden<NT, 0, 2>, lds)) return rc;
-            hipLaunchKernelGGL((k_hidden<NT, 0, 2>), dim3(nM * nN), dim3(256), lds, st, a);
-        } else {
-            if (int rc = set_lds(k_hidden<NT, 1, 2>, lds)) return rc;
-            hipLaunchKernelGGL((k_hidden<NT, 1, 2>), dim3(nM * nN), dim3(256), lds, st, a);
-        }
-    } else {
-#define QBM_L(CM)                                                                               \
-    {                                                                                           \
-        if (int rc = set_lds(k_hidden<NT, 0, CM>, lds)) return rc;                              \
-        hipLaunchKernelGGL((k_hidden<NT, 0, CM>), dim3(nM * nN), dim3(256), lds, st, a);        \
+    constexpr int ASZ = (int)sizeof(TA);
+    HiddenArgs a{v, y, P->W, P->d, P->U, p, s, s8, B, P->V, P->H, P->C, panel_for<ASZ>(P->V), seed, offset, row0,
+                 (P->H % 4 == 0) && (!p || aligned16(p)) && (!s || aligned16(s)) && (!s8 || aligned16(s8)) &&
+                     aligned16(P->d) && aligned16(P->U)};
+    // LDS-DMA path: whole 16-k pieces, 16-byte aligned units, descriptors below 2 GiB
+    const bool fast = (P->V % 16 == 0) && aligned16(v) && (P->H % 4 == 0) && aligned16(P->W) &&
+                      small2g((long)B * P->V, ASZ) && small2g((long)P->V * P->H, 4);
+    const int nM = (B + 16 * MT - 1) / (16 * MT), nN = (P->H + 16 * NT - 1) / (16 * NT);
+    const size_t lds = strip_lds_bytes<MT, NT, ASZ>(a.KP);
+#define QBM_LAUNCH(F, MODE, CM)                                                                  \
+    {                                                                                            \
+        if (int rc = set_lds(k_hidden<TA, F, MODE, CM>, lds)) return rc;                         \
+        hipLaunchKernelGGL((k_hidden<TA, F, MODE, CM>), dim3(nM * nN), dim3(256), lds, st, a);   \
     }
+    if (mode != 0 || !y) {  // no class term: the class-count bucket is irrelevant
+        if (mode == 0) { if (fast) QBM_LAUNCH(true, 0, 2) else QBM_LAUNCH(false, 0, 2) }
+        else { if (fast) QBM_LAUNCH(true, 1, 2) else QBM_LAUNCH(false, 1, 2) }
+    } else {
+#define QBM_L(CM) { if (fast) QBM_LAUNCH(true, 0, CM) else QBM_LAUNCH(false, 0, CM) }
         QBM_DISPATCH_CM(P->C, QBM_L);
 #undef QBM_L
     }
+#undef QBM_LAUNCH
     QBM_CHECK_LAUNCH("k_hidden");
     return QBM_OK;
 }
 
-// sample_visible, optionally with the class conditional riding along as aux workgroups
-int launch_visible(const qbm_rbm_params* P, const float* h, int B, float* p_v, float* v_sample, float* p_y,
-                   float* y1hot, uint64_t seed, uint64_t offset_v, uint64_t offset_y, uint32_t row0, hipStream_t st)
+int launch_hidden(const qbm_rbm_params* P, const void* v, int v_dtype, const float* y, int B, float* p, float* s,
+                  uint8_t* s8, int mode, uint64_t seed, uint64_t offset, uint32_t row0, hipStream_t st)
 {
-    constexpr int NT = 4;
+    return v_dtype == QBM_U8 ? launch_hidden_t<uint8_t>(P, v, y, B, p, s, s8, mode, seed, offset, row0, st)
+                             : launch_hidden_t<float>(P, v, y, B, p, s, s8, mode, seed, offset, row0, st);
+}
+
+// sample_visible, optionally with the class conditional riding along as aux workgroups
+template <class TA>
+int launch_visible_t(const qbm_rbm_params* P, const void* h, int B, float* p_v, float* v_s, uint8_t* v_s8, float* p_y,
+                     float* y1hot, uint64_t seed, uint64_t offset_v, uint64_t offset_y, uint32_t row0, hipStream_t st)
+{
+    constexpr int ASZ = (int)sizeof(TA);
     const bool with_class = p_y || y1hot;
-    const int nM = (B + 15) / 16, nN = (P->V + 16 * NT - 1) / (16 * NT);
-    VisibleArgs a{h, P->W, P->b, p_v, v_sample, B, P->V, P->H, panel_for<NT>(P->H), seed, offset_v, row0,
-                  (P->H % 4 == 0) && aligned16(h), (P->H % 4 == 0) && aligned16(P->W),
-                  (P->V % 4 == 0) && (!p_v || aligned16(p_v)) && (!v_sample || aligned16(v_sample)) && aligned16(P->b),
+    const int nM = (B + 16 * MT - 1) / (16 * MT), nN = (P->V + 16 * NT - 1) / (16 * NT);
+    VisibleArgs a{h, P->W, P->b, p_v, v_s, v_s8, B, P->V, P->H, panel_for<ASZ>(P->H), seed, offset_v, row0,
+                  (P->V % 4 == 0) && (!p_v || aligned16(p_v)) && (!v_s || aligned16(v_s)) && (!v_s8 || aligned16(v_s8)) &&
+                      aligned16(P->b),
                   P->U, P->c, p_y, y1hot, P->C, offset_y, with_class ? (B + 7) / 8 : 0};
+    const bool fast = (P->H % 16 == 0) && aligned16(h) && aligned16(P->W) && small2g((long)B * P->H, ASZ) &&
+                      small2g((long)P->V * P->H, 4);
     const int grid = nM * nN + a.n_aux;
-    const size_t lds = sizeof(float) * strip_lds_floats<NT>(a.KP);
-#define QBM_L(CM)                                                                         \
-    {                                                                                     \
-        if (int rc = set_lds(k_visible<NT, CM>, lds)) return rc;                          \
-        hipLaunchKernelGGL((k_visible<NT, CM>), dim3(grid), dim3(256), lds, st, a);       \
+    const size_t lds = strip_lds_bytes<MT, NT, ASZ>(a.KP);
+#define QBM_LAUNCH(F, CM)                                                                   \
+    {                                                                                       \
+        if (int rc = set_lds(k_visible<TA, F, CM>, lds)) return rc;                         \
+        hipLaunchKernelGGL((k_visible<TA, F, CM>), dim3(grid), dim3(256), lds, st, a);      \
     }
+#define QBM_L(CM) { if (fast) QBM_LAUNCH(true, CM) else QBM_LAUNCH(false, CM) }
     if (!with_class) { QBM_L(2) }
     else { QBM_DISPATCH_CM(P->C, QBM_L); }
 #undef QBM_L
+#undef QBM_LAUNCH
     QBM_CHECK_LAUNCH("k_visible");
     return QBM_OK;
 }
 
-int launch_grad(int V, int H, int C, int B, const float* A0, const float* Y0, const float* P0, const float* A1,
-                const float* Y1, const float* P1, const qbm_rbm_grads* G, float* W_fused, const qbm_rbm_params* aux_fused,
-                float lr, float factor, float bs, float sparse, hipStream_t st)
+int launch_visible(const qbm_rbm_params* P, const void* h, int h_dtype, int B, float* p_v, float* v_s, uint8_t* v_s8,
+                   float* p_y, float* y1hot, uint64_t seed, uint64_t offset_v, uint64_t offset_y, uint32_t row0,
+                   hipStream_t st)
 {
-    constexpr int NT = 2;
-    const int nM = (V + 15) / 16, nN = (H + 16 * NT - 1) / (16 * NT);
+    return h_dtype == QBM_U8
+               ? launch_visible_t<uint8_t>(P, h, B, p_v, v_s, v_s8, p_y, y1hot, seed, offset_v, offset_y, row0, st)
+               : launch_visible_t<float>(P, h, B, p_v, v_s, v_s8, p_y, y1hot, seed, offset_v, offset_y, row0, st);
+}
+
+template <class T0, class T1>
+int launch_grad_t(int V, int H, int C, int B, const void* A0, const float* Y0, const float* P0, const void* A1,
+                  const float* Y1, const float* P1, const qbm_rbm_grads* G, float* W_fused, const qbm_rbm_params* aux_fused,
+                  float lr, float factor, float bs, float sparse, hipStream_t st)
+{
+    const int nM = (V + 16 * MT - 1) / (16 * MT), nN = (H + 16 * NT - 1) / (16 * NT);
     const bool want_b = G->gb || (aux_fused && aux_fused->b);
     const bool want_c = G->gc || (aux_fused && aux_fused->c);
     GradArgs a{A0, Y0, P0, A1, Y1, P1, G->gW, G->gb, G->gd, G->gU, G->gc, W_fused,
                aux_fused ? aux_fused->b : nullptr, aux_fused ? aux_fused->d : nullptr,
                aux_fused ? aux_fused->U : nullptr, aux_fused ? aux_fused->c : nullptr,
-               lr, factor, bs, sparse, B, V, H, C, panel_for<NT>(B),
-               (H + 63) / 64 + (want_b ? (V + 63) / 64 : 0) + (want_c ? 1 : 0), (H + 63) / 64, want_b ? (V + 63) / 64 : 0,
-               (V % 4 == 0) && aligned16(A0) && aligned16(A1), (H % 4 == 0) && aligned16(P0) && aligned16(P1),
+               lr, factor, bs, sparse, B, V, H, C, panel_for<4>(B),
+               nN, want_b ? nM : 0, want_c ? (C + 16 * NT - 1) / (16 * NT) : 0,
                (H % 4 == 0) && (!G->gW || aligned16(G->gW)) && (!W_fused || aligned16(W_fused))};
-    const int grid = nM * nN + a.n_aux;
-#define QBM_L(CM)                                                                                   \
-    {                                                                                               \
-        size_t lds = sizeof(float) * strip_lds_floats<NT>(a.KP);                                    \
-        const size_t aux = sizeof(float) * 4 * 2 * (CM + 1) * 64;                                   \
-        if (aux > lds) lds = aux;                                                                   \
-        if (int rc = set_lds(k_grad<NT, CM>, lds)) return rc;                                       \
-        hipLaunchKernelGGL((k_grad<NT, CM>), dim3(grid), dim3(256), lds, st, a);                    \
+    const bool fast = (B % 16 == 0) && (V % 16 == 0) && (H % 4 == 0) && aligned16(A0) && aligned16(A1) && aligned16(P0) &&
+                      aligned16(P1) && small2g((long)B * V, 4) && small2g((long)B * H, 4);
+    const int grid = a.nU + a.nB + a.nC + nM * nN;
+    const size_t lds = strip_lds_bytes<MT, NT, 4>(a.KP);  // the fp32 synthesised operands (kinds U, B, C) set the budget
+    if (fast) {
+        if (int rc = set_lds(k_grad<T0, T1, true>, lds)) return rc;
+        hipLaunchKernelGGL((k_grad<T0, T1, true>), dim3(grid), dim3(256), lds, st, a);
+    } else {
+        if (int rc = set_lds(k_grad<T0, T1, false>, lds)) return rc;
+        hipLaunchKernelGGL((k_grad<T0, T1, false>), dim3(grid), dim3(256), lds, st, a);
     }
-    QBM_DISPATCH_CM(C, QBM_L);
-#undef QBM_L
     QBM_CHECK_LAUNCH("k_grad");
     return QBM_OK;
+}
+
+int launch_grad(int V, int H, int C, int B, const void* A0, int d0, const float* Y0, const float* P0, const void* A1, int d1,
+                const float* Y1, const float* P1, const qbm_rbm_grads* G, float* W_fused, const qbm_rbm_params* aux_fused,
+                float lr, float factor, float bs, float sparse, hipStream_t st)
+{
+    if (C + 1 > 16 * MT) return fail(QBM_ERR_ARG, "two_phase_grad: C + 1 must fit one 32-row strip");
+#define QBM_G(T0, T1) launch_grad_t<T0, T1>(V, H, C, B, A0, Y0, P0, A1, Y1, P1, G, W_fused, aux_fused, lr, factor, bs, sparse, st)
+    if (d0 == QBM_U8) return d1 == QBM_U8 ? QBM_G(uint8_t, uint8_t) : QBM_G(uint8_t, float);
+    return d1 == QBM_U8 ? QBM_G(float, uint8_t) : QBM_G(float, float);
+#undef QBM_G
 }
 
 }  // namespace
@@ -727,11 +754,18 @@ const char* qbm_last_error(void) { return g_err; }
 int qbm_rbm_sample_hidden(const qbm_rbm_params* P, const float* v, const float* y1hot, int B, float* p_h,
                           float* h_sample, uint64_t seed, uint64_t offset, uint32_t row0, void* stream)
 {
+    return qbm_rbm_sample_hidden_ex(P, v, QBM_F32, y1hot, B, p_h, h_sample, nullptr, seed, offset, row0, stream);
+}
+
+int qbm_rbm_sample_hidden_ex(const qbm_rbm_params* P, const void* v, int v_dtype, const float* y1hot, int B, float* p_h,
+                             float* h_f32, uint8_t* h_u8, uint64_t seed, uint64_t offset, uint32_t row0, void* stream)
+{
     if (int rc = check_params(P)) return rc;
+    if (int rc = check_dtype(v_dtype)) return rc;
     if (B < 0) return fail(QBM_ERR_ARG, "B < 0");
     if (B == 0) return QBM_OK;
-    if (!v || (!p_h && !h_sample)) return fail(QBM_ERR_ARG, "sample_hidden: null input/output");
-    return launch_hidden(P, v, y1hot, B, p_h, h_sample, 0, seed, offset, row0, (hipStream_t)stream);
+    if (!v || (!p_h && !h_f32 && !h_u8)) return fail(QBM_ERR_ARG, "sample_hidden: null input/output");
+    return launch_hidden(P, v, v_dtype, y1hot, B, p_h, h_f32, h_u8, 0, seed, offset, row0, (hipStream_t)stream);
 }
 
 int qbm_rbm_hidden_preact(const qbm_rbm_params* P, const float* x, int B, float* pre, void* stream)
@@ -740,7 +774,7 @@ int qbm_rbm_hidden_preact(const qbm_rbm_params* P, const float* x, int B, float*
     if (B < 0) return fail(QBM_ERR_ARG, "B < 0");
     if (B == 0) return QBM_OK;
     if (!x || !pre) return fail(QBM_ERR_ARG, "hidden_preact: null input/output");
-    return launch_hidden(P, x, nullptr, B, pre, nullptr, 1, 0, 0, 0, (hipStream_t)stream);
+    return launch_hidden(P, x, QBM_F32, nullptr, B, pre, nullptr, nullptr, 1, 0, 0, 0, (hipStream_t)stream);
 }
 
 int qbm_rbm_sample_visible(const qbm_rbm_params* P, const float* h, int B, float* p_v, float* v_sample,
@@ -750,18 +784,21 @@ int qbm_rbm_sample_visible(const qbm_rbm_params* P, const float* h, int B, float
     if (B < 0) return fail(QBM_ERR_ARG, "B < 0");
     if (B == 0) return QBM_OK;
     if (!h || (!p_v && !v_sample)) return fail(QBM_ERR_ARG, "sample_visible: null input/output");
-    return launch_visible(P, h, B, p_v, v_sample, nullptr, nullptr, seed, offset, 0, row0, (hipStream_t)stream);
+    return launch_visible(P, h, QBM_F32, B, p_v, v_sample, nullptr, nullptr, nullptr, seed, offset, 0, row0,
+                          (hipStream_t)stream);
 }
 
-int qbm_rbm_sample_visible_class(const qbm_rbm_params* P, const float* h, int B, float* p_v, float* v_sample,
-                                 float* p_y, float* y1hot, uint64_t seed, uint64_t offset_v, uint64_t offset_y,
-                                 uint32_t row0, void* stream)
+int qbm_rbm_sample_visible_class_ex(const qbm_rbm_params* P, const void* h, int h_dtype, int B, float* p_v, float* v_f32,
+                                    uint8_t* v_u8, float* p_y, float* y1hot, uint64_t seed, uint64_t offset_v,
+                                    uint64_t offset_y, uint32_t row0, void* stream)
 {
     if (int rc = check_params(P)) return rc;
+    if (int rc = check_dtype(h_dtype)) return rc;
     if (B < 0) return fail(QBM_ERR_ARG, "B < 0");
     if (B == 0) return QBM_OK;
-    if (!h || (!p_v && !v_sample) || (!p_y && !y1hot)) return fail(QBM_ERR_ARG, "sample_visible_class: null input/output");
-    return launch_visible(P, h, B, p_v, v_sample, p_y, y1hot, seed, offset_v, offset_y, row0, (hipStream_t)stream);
+    if (!h || (!p_v && !v_f32 && !v_u8)) return fail(QBM_ERR_ARG, "sample_visible_class: null input/output");
+    return launch_visible(P, h, h_dtype, B, p_v, v_f32, v_u8, p_y, y1hot, seed, offset_v, offset_y, row0,
+                          (hipStream_t)stream);
 }
 
 int qbm_rbm_sample_class(const qbm_rbm_params* P, const float* h, int B, float* p_y, float* y1hot, uint64_t seed,
@@ -771,8 +808,8 @@ int qbm_rbm_sample_class(const qbm_rbm_params* P, const float* h, int B, float* 
     if (B < 0) return fail(QBM_ERR_ARG, "B < 0");
     if (B == 0) return QBM_OK;
     if (!h || (!p_y && !y1hot)) return fail(QBM_ERR_ARG, "sample_class: null input/output");
-#define QBM_L(CM)                                                                                             \
-    hipLaunchKernelGGL((k_class<CM>), dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, h, P->U, P->c, p_y, \
+#define QBM_L(CM)                                                                                                  \
+    hipLaunchKernelGGL((k_class<float, CM>), dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, h, P->U, P->c, p_y, \
                        y1hot, B, P->H, P->C, seed, offset, row0)
     QBM_DISPATCH_CM(P->C, QBM_L);
 #undef QBM_L
@@ -787,7 +824,7 @@ int qbm_rbm_free_energy(const qbm_rbm_params* P, const float* x, int B, float* p
     if (B < 0) return fail(QBM_ERR_ARG, "B < 0");
     if (B == 0) return QBM_OK;
     if (!x || !pre_ws || (!neg_free_energy && !p_y_given_x)) return fail(QBM_ERR_ARG, "free_energy: null buffer");
-    if (int rc = launch_hidden(P, x, nullptr, B, pre_ws, nullptr, 1, 0, 0, 0, (hipStream_t)stream)) return rc;
+    if (int rc = launch_hidden(P, x, QBM_F32, nullptr, B, pre_ws, nullptr, nullptr, 1, 0, 0, 0, (hipStream_t)stream)) return rc;
 #define QBM_L(CM)                                                                                               \
     hipLaunchKernelGGL((k_free_energy<CM>), dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, pre_ws, P->U,   \
                        P->c, neg_free_energy, p_y_given_x, B, P->H, P->C)
@@ -823,18 +860,19 @@ int qbm_rbm_disc_class_grad(const qbm_rbm_params* P, const float* pre, const flo
     return QBM_OK;
 }
 
-int qbm_rbm_two_phase_grad(int V, int H, int C, int B, const float* A0, const float* Y0, const float* P0,
-                           const float* A1, const float* Y1, const float* P1, const qbm_rbm_grads* G, float* W_fused,
-                           const qbm_rbm_params* aux_fused, float lr, float factor, float batch_size,
+int qbm_rbm_two_phase_grad(int V, int H, int C, int B, const void* A0, int a0_dtype, const float* Y0, const float* P0,
+                           const void* A1, int a1_dtype, const float* Y1, const float* P1, const qbm_rbm_grads* G,
+                           float* W_fused, const qbm_rbm_params* aux_fused, float lr, float factor, float batch_size,
                            float sparse_constant, void* stream)
 {
     if (V <= 0 || H <= 0 || C <= 0 || B <= 0) return fail(QBM_ERR_ARG, "two_phase_grad: non-positive dims");
-    if (C > QBM_MAX_CLASSES) return fail(QBM_ERR_ARG, "C exceeds QBM_MAX_CLASSES");
+    if (int rc = check_dtype(a0_dtype)) return rc;
+    if (int rc = check_dtype(a1_dtype)) return rc;
     if (!A0 || !P0 || !A1 || !P1 || !G) return fail(QBM_ERR_ARG, "two_phase_grad: null operand");
     if (!G->gW && !W_fused) return fail(QBM_ERR_ARG, "two_phase_grad: neither gW nor fused W given");
     if ((W_fused || aux_fused) && !(batch_size > 0.f)) return fail(QBM_ERR_ARG, "two_phase_grad: batch_size must be positive");
-    return launch_grad(V, H, C, B, A0, Y0, P0, A1, Y1, P1, G, W_fused, aux_fused, lr, factor, batch_size,
-                       sparse_constant, (hipStream_t)stream);
+    return launch_grad(V, H, C, B, A0, a0_dtype, Y0, P0, A1, a1_dtype, Y1, P1, G, W_fused, aux_fused, lr, factor,
+                       batch_size, sparse_constant, (hipStream_t)stream);
 }
 
 int qbm_rbm_update(const qbm_rbm_params* P, const qbm_rbm_grads* G, float lr, float factor, float batch_size,
@@ -854,11 +892,22 @@ int qbm_rbm_update(const qbm_rbm_params* P, const qbm_rbm_grads* G, float lr, fl
     return QBM_OK;
 }
 
-int qbm_rbm_cd_chain(const qbm_rbm_params* P, const float* v0, const float* y0, int B, int k, uint64_t seed,
-                     uint64_t offset, uint32_t row0, float* chain_v, float* chain_y, const qbm_rbm_cd_workspace* ws,
+int qbm_f32_to_u8(const float* x, uint8_t* y, long n, void* stream)
+{
+    if (n < 0) return fail(QBM_ERR_ARG, "f32_to_u8: n < 0");
+    if (n == 0) return QBM_OK;
+    if (!x || !y) return fail(QBM_ERR_ARG, "f32_to_u8: null buffer");
+    hipLaunchKernelGGL(k_f32_to_u8, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    QBM_CHECK_LAUNCH("k_f32_to_u8");
+    return QBM_OK;
+}
+
+int qbm_rbm_cd_chain(const qbm_rbm_params* P, const void* v0, int v0_dtype, const float* y0, int B, int k, uint64_t seed,
+                     uint64_t offset, uint32_t row0, uint8_t* chain_v, float* chain_y, const qbm_rbm_cd_workspace* ws,
                      void* stream)
 {
     if (int rc = check_params(P)) return rc;
+    if (int rc = check_dtype(v0_dtype)) return rc;
     if (B <= 0) return B == 0 ? QBM_OK : fail(QBM_ERR_ARG, "B < 0");
     if (k < 1) return fail(QBM_ERR_ARG, "cd_chain: k must be >= 1");
     if (!v0 || !y0 || !ws || !ws->ph0 || !ws->h || !ws->vk || !ws->yk || !ws->phk)
@@ -867,19 +916,20 @@ int qbm_rbm_cd_chain(const qbm_rbm_params* P, const float* v0, const float* y0, 
     hipStream_t st = (hipStream_t)stream;
     if (chain_v) {
         // positive phase on the data (probabilities only), negative chain from the persistent state
-        if (int rc = launch_hidden(P, v0, y0, B, ws->ph0, nullptr, 0, seed, offset, row0, st)) return rc;
-        if (int rc = launch_hidden(P, chain_v, chain_y, B, nullptr, ws->h, 0, seed, offset, row0, st)) return rc;
+        if (int rc = launch_hidden(P, v0, v0_dtype, y0, B, ws->ph0, nullptr, nullptr, 0, seed, offset, row0, st)) return rc;
+        if (int rc = launch_hidden(P, chain_v, QBM_U8, chain_y, B, nullptr, nullptr, ws->h, 0, seed, offset, row0, st)) return rc;
     } else {
-        if (int rc = launch_hidden(P, v0, y0, B, ws->ph0, ws->h, 0, seed, offset, row0, st)) return rc;
+        if (int rc = launch_hidden(P, v0, v0_dtype, y0, B, ws->ph0, nullptr, ws->h, 0, seed, offset, row0, st)) return rc;
     }
     for (int t = 1; t <= k; ++t) {
         const uint64_t o = offset + 3ull * (uint64_t)t;
         // v_t and y_t both depend on h_{t-1} only: one launch (class conditional as aux workgroups)
-        if (int rc = launch_visible(P, ws->h, B, nullptr, ws->vk, nullptr, ws->yk, seed, o - 2, o - 1, row0, st)) return rc;
-        if (int rc = launch_hidden(P, ws->vk, ws->yk, B, ws->phk, ws->h, 0, seed, o, row0, st)) return rc;
+        if (int rc = launch_visible(P, ws->h, QBM_U8, B, nullptr, nullptr, ws->vk, nullptr, ws->yk, seed, o - 2, o - 1, row0, st))
+            return rc;
+        if (int rc = launch_hidden(P, ws->vk, QBM_U8, ws->yk, B, ws->phk, nullptr, ws->h, 0, seed, o, row0, st)) return rc;
     }
     if (chain_v) {
-        hipError_t e = hipMemcpyAsync(chain_v, ws->vk, sizeof(float) * (size_t)B * P->V, hipMemcpyDeviceToDevice, st);
+        hipError_t e = hipMemcpyAsync(chain_v, ws->vk, (size_t)B * P->V, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(chain_v)");
         e = hipMemcpyAsync(chain_y, ws->yk, sizeof(float) * (size_t)B * P->C, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(chain_y)");
@@ -887,21 +937,22 @@ int qbm_rbm_cd_chain(const qbm_rbm_params* P, const float* v0, const float* y0, 
     return QBM_OK;
 }
 
-int qbm_rbm_cd_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const float* v0, const float* y0, int B, int k,
-                    uint64_t seed, uint64_t offset, uint32_t row0, float* chain_v, float* chain_y,
+int qbm_rbm_cd_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void* v0, int v0_dtype, const float* y0, int B,
+                    int k, uint64_t seed, uint64_t offset, uint32_t row0, uint8_t* chain_v, float* chain_y,
                     const qbm_rbm_cd_workspace* ws, int fuse_update, float lr, float factor, float batch_size,
                     float sparse_constant, void* stream)
 {
     if (!G) return fail(QBM_ERR_ARG, "cd_step: grads is null");
     if (!fuse_update && (!G->gW || !G->gb || !G->gd || !G->gU || !G->gc))
         return fail(QBM_ERR_ARG, "cd_step: all gradient blocks are required without fuse_update");
-    if (int rc = qbm_rbm_cd_chain(P, v0, y0, B, k, seed, offset, row0, chain_v, chain_y, ws, stream)) return rc;
+    if (int rc = qbm_rbm_cd_chain(P, v0, v0_dtype, y0, B, k, seed, offset, row0, chain_v, chain_y, ws, stream)) return rc;
     if (B == 0) return QBM_OK;
     if (!(batch_size > 0.f)) return fail(QBM_ERR_ARG, "cd_step: batch_size must be positive");
     qbm_rbm_grads g = *G;
     if (fuse_update) g.gW = nullptr;  // the whole update happens inside the gradient launch
-    return launch_grad(P->V, P->H, P->C, B, v0, y0, ws->ph0, ws->vk, ws->yk, ws->phk, &g, fuse_update ? P->W : nullptr,
-                       fuse_update ? P : nullptr, lr, factor, batch_size, sparse_constant, (hipStream_t)stream);
+    return launch_grad(P->V, P->H, P->C, B, v0, v0_dtype, y0, ws->ph0, ws->vk, QBM_U8, ws->yk, ws->phk, &g,
+                       fuse_update ? P->W : nullptr, fuse_update ? P : nullptr, lr, factor, batch_size, sparse_constant,
+                       (hipStream_t)stream);
 }
 
 int qbm_rbm_disc_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const float* x, const int32_t* labels, int B,
@@ -922,9 +973,9 @@ int qbm_rbm_disc_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const flo
     g.gb = nullptr;  // reference: visible_bias_grad = 0 (src/ClassificationRBM.py:138)
     g.gc = nullptr;  // written by disc_class_grad below
     if (fuse) g.gW = nullptr;
-    // W may be fused; U, c, d wait for disc_class_grad, so the aux workgroups only write gradients here
-    if (int rc = launch_grad(P->V, P->H, P->C, B, x, ws->onehot, ws->pos, x, nullptr, ws->neg, &g, fuse ? P->W : nullptr,
-                             nullptr, lr, factor, batch_size, sparse_constant, (hipStream_t)stream))
+    // W may be fused; U, c, d wait for disc_class_grad, so the U/B/C workgroups only write gradients here
+    if (int rc = launch_grad(P->V, P->H, P->C, B, x, QBM_F32, ws->onehot, ws->pos, x, QBM_F32, nullptr, ws->neg, &g,
+                             fuse ? P->W : nullptr, nullptr, lr, factor, batch_size, sparse_constant, (hipStream_t)stream))
         return rc;
     if (int rc = qbm_rbm_disc_class_grad(P, ws->pre, p_y, labels, B, G->gU, G->gc, stream)) return rc;
     if (apply_update) {

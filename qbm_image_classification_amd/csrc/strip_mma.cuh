@@ -1,172 +1,269 @@
 // strip_mma.cuh -- the K-quartered strip contraction every dense product of the path runs on.
 //
-// One workgroup = 4 wavefronts = the 4 SIMDs of one CU.  It owns a 16 x (16*NT) strip of the
+// One workgroup = 4 wavefronts = the 4 SIMDs of one CU.  It owns a (16*MT) x (16*NT) strip of the
 // output.  Wave q contracts K-quarter q ([Q] of the numerical contract) with
-// v_mfma_f32_16x16x4_f32, NT independent accumulators per wave (NT >= 2 reaches the MFMA issue
+// v_mfma_f32_16x16x4_f32, MT*NT independent accumulators per wave (>= 2 reaches the MFMA issue
 // rate: 32-cycle issue vs 40-cycle dependent latency).  The four partial strips meet in LDS and
 // are added ((q0+q1)+q2)+q3; the caller's epilogue then runs on a row-major thread map
 // (thread -> one row, 4 consecutive columns) so that one Philox4x32 call serves one thread and
 // stores are 16 B wide.
 //
-// Operand tiles go through LDS in two images chosen so that the per-lane MFMA fragment read is a
-// conflict-free, lane-linear ds_read_b32 of 64 consecutive dwords:
-//   "k4"  image (operand whose K index is contiguous in memory: activations [B, features], and W
-//         when it is applied transposed): float4 slot (k/4)*16 + r  -> fragment dword
-//         s*64 + (lane&15)*4 + (lane>>4)
-//   "lin" image (operand whose M/N index is contiguous: W[k][n], P[b][n], data[b][m] for the
-//         gradient): dword k*16 + r -> fragment dword s*64 + lane
-// Both images are filled 1 KiB per wave-instruction in lane order (slot = piece*64 + lane), i.e.
-// in the order an LDS-DMA (global_load_lds_dwordx4) writes.
+// What bounds these kernels on MI355X is the L2 -> LDS staging of the operand strips (measured with
+// s_memtime stamps, tools/microbench/stamp_strip.hip), not the MFMA pipe, so the layout minimises
+// staged bytes per workgroup:
+//   * the B operand (W, or the probabilities in the gradient) is fp32;
+//   * the A operand may be uint8: Gibbs states are {0,1}, a byte per unit is exact and 4x smaller;
+//     it is widened to fp32 in registers (v_cvt_f32_ubyte) right before the MFMA;
+//   * MT = 2, NT = 1: two row tiles share every staged B fragment.
+//
+// Operand tiles go through LDS in images filled by LDS-DMA (global_load_lds_dwordx4: 16 B per lane,
+// no VGPR round trip, wave-uniform LDS base + lane*16, per-lane global address):
+//   fp32 "k4"  image (K contiguous in memory): float4 slot piece*64 + (k4 in piece)*16 + r
+//               -> MFMA fragment of k-step s: dword s*64 + (lane&15)*4 + (lane>>4)
+//   fp32 "lin" image (M/N contiguous):          dword k*16 + r -> fragment dword s*64 + lane
+//   u8   "k4"  image: 16-byte slot piece*16 + r = 16 consecutive k of one row -> one ds_read_b128 per
+//               piece, byte (lane>>4) of dword s is k-step s
+//   u8   "lin" image: 16-byte slot k = 16 consecutive m -> ds_read_u8 at (4s + (lane>>4))*16 + (lane&15)
+// A "piece" is 16 consecutive k (4 MFMA k-steps).  Out-of-range k / rows are staged as zeros from a
+// 16-byte zero page, so the MFMA loop needs no masks (fmaf(0, b, acc) == acc).
 #pragma once
 #include "qbm_device.cuh"
 
+// diagnostic builds (tools/microbench) define QBM_STAMP(i) to record s_memtime at phase boundaries;
+// in the product it expands to nothing
+#ifndef QBM_STAMP
+#define QBM_STAMP(i)
+#endif
+// diagnostic builds may also define QBM_DIAG_MODE as an int expression: 1 = one vmcnt(0) before the MFMA loop
+// instead of the half-way counted wait, 3 = no MFMA loop.  0 in the product (the branches fold away).
+#ifndef QBM_DIAG_MODE
+#define QBM_DIAG_MODE 0
+#endif
+
 namespace qbm {
 
-// 16 zero bytes: the LDS-DMA source of every out-of-range fragment (rows beyond M/N, k beyond the quarter)
+// 16 zero bytes: the LDS-DMA source of every out-of-range fragment
 static __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
-// LDS-DMA: 16 B per lane, global -> LDS with no VGPR destination.  The LDS address is the wave-uniform
-// `lds_piece` + lane*16; the global source is per lane (cdna_hip_programming.md section 5, Caveat).
-__device__ __forceinline__ void glds16(const float* g, float* lds_piece)
+// LDS-DMA through a buffer descriptor: 16 B per lane, global -> LDS with no VGPR destination
+// (buffer_load_dwordx4 ... offen lds).  The LDS address is the wave-uniform `lds_piece` (M0) + lane*16;
+// `voff` is this lane's byte offset into the buffer.  An offset at or beyond the descriptor's size reads
+// as zeros: that is how rows beyond the operand and the tail of a K quarter are staged, with no
+// per-lane address arithmetic beyond one add per instruction.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr unsigned kOOB = 0x80000000u;  // operands are < 2 GiB (checked on the host), so this is out of range
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes)
 {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds_piece, 16, 0, 0);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 
-// ---- operand views: get() returns 4 consecutive elements, zero outside the operand -----------
+__device__ __forceinline__ void blds16(rsrc_t r, unsigned voff, void* lds_piece)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_piece, 16, voff, 0, 0, 0);
+}
 
-// element(row, k) = p[row*ld + k]; 4 consecutive k
+// this lane's walk over one 16-wide tile of an operand: byte offset of its 16 B in the first DMA
+// instruction, the advance per instruction, and the K index it starts at (for the tail test of u8 quads)
+struct DmaLane {
+    unsigned voff, step;
+    int k, kstep;
+};
+
+// ---- operand views -------------------------------------------------------------------------------
+// rsrc()/lane0(): buffer descriptor and per-lane walk of the LDS-DMA (FAST) path; the host selects it only
+//         when every 16-byte unit is aligned and wholly inside or wholly outside the operand.
+// get():  the same 16 bytes as a value, branch-free (clamped indices + selects), for the generic path.
+//   `r0` = first row/column of the 16-wide tile, `kb` = first k staged, lane = 0..63.
+
+// fp32, element(row, k) = p[row*ld + k]  (K contiguous: "k4" image)
 struct ViewKContig {
+    using elem = float;
+    static constexpr bool kK4 = true;
     const float* p;
     long ld;
     int rows;
-    bool vec;  // ld % 4 == 0 and p 16-byte aligned
-    // LDS-DMA staging is legal for this strip: every float4 is wholly inside or wholly outside
-    __device__ __forceinline__ bool dma(int /*c0*/, int /*width*/, int K) const { return vec && (K & 3) == 0; }
-    __device__ __forceinline__ const float* addr(int row, int k, int kend) const
+    __device__ __forceinline__ rsrc_t rsrc() const { return make_rsrc(p, (unsigned)(rows * ld * 4)); }
+    __device__ __forceinline__ DmaLane lane0(int r0, int kb, int lane) const  // rows beyond the operand are out of range
     {
-        return (row < rows && k < kend) ? p + (long)row * ld + k : g_zero16;
+        const int row = r0 + (lane & 15), k = kb + 4 * (lane >> 4);
+        return DmaLane{(unsigned)((row * (int)ld + k) * 4), 64u, k, 16};
     }
-    __device__ __forceinline__ float4 get(int row, int k, int kend) const
+    __device__ __forceinline__ float4 get(int r0, int kb, int kend, int slot) const  // slot = piece*64 + lane
     {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < rows && k < kend) {
-            const float* q = p + (long)row * ld + k;
-            if (vec && k + 3 < kend) {
-                v = *reinterpret_cast<const float4*>(q);
-            } else {
-                v.x = q[0];
-                if (k + 1 < kend) v.y = q[1];
-                if (k + 2 < kend) v.z = q[2];
-                if (k + 3 < kend) v.w = q[3];
-            }
-        }
+        const int row = r0 + (slot & 15), k = kb + 4 * (slot >> 4);
+        const float* q = p + (long)min(row, rows - 1) * ld;
+        const bool rok = row < rows;
+        const int km = max(kend - 1, 0);
+        float4 v;
+        v.x = q[min(k, km)]; v.y = q[min(k + 1, km)]; v.z = q[min(k + 2, km)]; v.w = q[min(k + 3, km)];
+        v.x = (rok && k < kend) ? v.x : 0.f;     v.y = (rok && k + 1 < kend) ? v.y : 0.f;
+        v.z = (rok && k + 2 < kend) ? v.z : 0.f; v.w = (rok && k + 3 < kend) ? v.w : 0.f;
         return v;
     }
 };
 
-// element(k, c) = p[k*ld + c]; 4 consecutive c
+// fp32, element(k, c) = p[k*ld + c]  (M/N contiguous: "lin" image).  p == nullptr reads as zeros.
 struct ViewCContig {
+    using elem = float;
+    static constexpr bool kK4 = false;
     const float* p;
     long ld;
     int cols;
-    bool vec;
-    __device__ __forceinline__ bool dma(int /*c0*/, int /*width*/, int /*K*/) const { return vec && (cols & 3) == 0; }
-    __device__ __forceinline__ const float* addr(int k, int c, int kend) const
+    int krows;  // number of k rows the buffer holds (its size is krows*ld*4 bytes)
+    __device__ __forceinline__ rsrc_t rsrc() const { return make_rsrc(p, (unsigned)(krows * ld * 4)); }
+    __device__ __forceinline__ DmaLane lane0(int c0, int kb, int lane) const
     {
-        return (k < kend && c < cols) ? p + (long)k * ld + c : g_zero16;
+        const int c = c0 + 4 * (lane & 3), k = kb + (lane >> 2);
+        return DmaLane{c < cols ? (unsigned)((k * (int)ld + c) * 4) : kOOB, (unsigned)(64 * ld), k, 16};
     }
-    __device__ __forceinline__ float4 get(int k, int c, int kend) const
+    __device__ __forceinline__ float4 get(int c0, int kb, int kend, int slot) const
     {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < kend && c < cols) {
-            const float* q = p + (long)k * ld + c;
-            if (vec && c + 3 < cols) {
-                v = *reinterpret_cast<const float4*>(q);
-            } else {
-                v.x = q[0];
-                if (c + 1 < cols) v.y = q[1];
-                if (c + 2 < cols) v.z = q[2];
-                if (c + 3 < cols) v.w = q[3];
-            }
-        }
+        const int c = c0 + 4 * (slot & 3), k = kb + (slot >> 2);
+        const float* q = p ? p + (long)min(k, max(kend - 1, 0)) * ld : g_zero16;
+        const bool kok = p && k < kend;
+        const int cm = p ? cols - 1 : 0;
+        float4 v;
+        v.x = q[min(c, cm)]; v.y = q[min(c + 1, cm)]; v.z = q[min(c + 2, cm)]; v.w = q[min(c + 3, cm)];
+        v.x = (kok && c < cols) ? v.x : 0.f;     v.y = (kok && c + 1 < cols) ? v.y : 0.f;
+        v.z = (kok && c + 2 < cols) ? v.z : 0.f; v.w = (kok && c + 3 < cols) ? v.w : 0.f;
         return v;
     }
 };
 
-// Gradient A operand, augmented: m in [0,V) -> data[k][m]; [V,V+C) -> onehot/prob Y[k][m-V] (if Y);
-// m == V+C -> 1 (column sums of the B operand).  element(k, m), 4 consecutive m.
-struct ViewAugData {
-    const float* data;  // [B, V]
-    const float* Y;     // [B, C] or nullptr
-    int V, C;
-    bool vec;
-    __device__ __forceinline__ bool dma(int c0, int width, int /*K*/) const { return vec && c0 + width <= V; }
-    __device__ __forceinline__ const float* addr(int k, int m, int kend) const
+// u8, element(row, k) = p[row*ld + k]  (K contiguous).  One DMA instruction stages 4 pieces (64 k).
+struct ViewKContigU8 {
+    using elem = uint8_t;
+    static constexpr bool kK4 = true;
+    const uint8_t* p;
+    long ld;
+    int rows;
+    __device__ __forceinline__ rsrc_t rsrc() const { return make_rsrc(p, (unsigned)(rows * ld)); }
+    __device__ __forceinline__ DmaLane lane0(int r0, int kb, int lane) const
     {
-        return (k < kend) ? data + (long)k * V + m : g_zero16;
+        const int row = r0 + (lane & 15), k = kb + 16 * (lane >> 4);
+        return DmaLane{(unsigned)(row * (int)ld + k), 64u, k, 64};
     }
-    __device__ __forceinline__ float one(int k, int m) const
+    __device__ __forceinline__ uint4 get(int r0, int kb, int kend, int slot) const  // slot = quad*64 + lane
     {
-        if (m < V) return data[(long)k * V + m];
-        if (m < V + C) return Y ? Y[(long)k * C + (m - V)] : 0.f;
-        return (m == V + C) ? 1.f : 0.f;
-    }
-    __device__ __forceinline__ float4 get(int k, int m, int kend) const
-    {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < kend) {
-            if (vec && m + 3 < V) {
-                v = *reinterpret_cast<const float4*>(data + (long)k * V + m);
-            } else {
-                v.x = one(k, m); v.y = one(k, m + 1); v.z = one(k, m + 2); v.w = one(k, m + 3);
+        const int row = r0 + (slot & 15), k = kb + 16 * (slot >> 4);
+        const uint8_t* q = p + (long)min(row, rows - 1) * ld;
+        const bool rok = row < rows;
+        const int km = max(kend - 1, 0);
+        uint32_t w[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            w[d] = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int kk = k + 4 * d + b;
+                const uint32_t v = q[min(kk, km)];
+                w[d] |= ((rok && kk < kend) ? v : 0u) << (8 * b);
             }
         }
-        return v;
+        return make_uint4(w[0], w[1], w[2], w[3]);
     }
 };
 
-// Gradient B operand, augmented: n in [0,H) -> P[k][n]; n == H -> 1 (column sums of the A operand).
-struct ViewAugProb {
-    const float* P;  // [B, H]
-    int H;
-    bool ones;
-    bool vec;
-    __device__ __forceinline__ bool dma(int c0, int width, int /*K*/) const { return vec && c0 + width <= H; }
-    __device__ __forceinline__ const float* addr(int k, int n, int kend) const
+// u8, element(k, c) = p[k*ld + c]  (M contiguous).  One DMA instruction stages 64 k of one 16-wide tile.
+struct ViewCContigU8 {
+    using elem = uint8_t;
+    static constexpr bool kK4 = false;
+    const uint8_t* p;
+    long ld;
+    int cols;
+    int krows;
+    __device__ __forceinline__ rsrc_t rsrc() const { return make_rsrc(p, (unsigned)(krows * ld)); }
+    __device__ __forceinline__ DmaLane lane0(int c0, int kb, int lane) const
     {
-        return (k < kend) ? P + (long)k * H + n : g_zero16;
+        const int k = kb + lane;
+        return DmaLane{c0 < cols ? (unsigned)(k * (int)ld + c0) : kOOB, (unsigned)(64 * ld), k, 64};
     }
-    __device__ __forceinline__ float one(int k, int n) const
+    __device__ __forceinline__ uint4 get(int c0, int kb, int kend, int slot) const
     {
-        if (n < H) return P[(long)k * H + n];
-        return (ones && n == H) ? 1.f : 0.f;
-    }
-    __device__ __forceinline__ float4 get(int k, int n, int kend) const
-    {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < kend) {
-            if (vec && n + 3 < H) {
-                v = *reinterpret_cast<const float4*>(P + (long)k * H + n);
-            } else {
-                v.x = one(k, n); v.y = one(k, n + 1); v.z = one(k, n + 2); v.w = one(k, n + 3);
+        const int k = kb + slot;
+        const uint8_t* q = p + (long)min(k, max(kend - 1, 0)) * ld;
+        const bool kok = k < kend;
+        uint32_t w[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            w[d] = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int c = c0 + 4 * d + b;
+                const uint32_t v = q[min(c, cols - 1)];
+                w[d] |= ((kok && c < cols) ? v : 0u) << (8 * b);
             }
         }
-        return v;
+        return make_uint4(w[0], w[1], w[2], w[3]);
     }
 };
 
-// LDS floats needed by one workgroup for panel length KP (multiple of 16)
-template <int NT>
-__host__ __device__ constexpr int strip_lds_floats(int KP) { return 4 * (NT + 1) * 16 * KP; }
+// Gradient A operand for the class-weight / hidden-bias rows: element(k, m) = Y[k][m] for m < C (Y may
+// be null = zeros), 1 for m == C (its product with P is the column sum of P), 0 beyond.  Generic path.
+struct ViewAugY {
+    using elem = float;
+    static constexpr bool kK4 = false;
+    const float* Y;  // [B, C] or nullptr
+    int C;
+    __device__ __forceinline__ rsrc_t rsrc() const { return make_rsrc(nullptr, 0); }
+    __device__ __forceinline__ DmaLane lane0(int, int, int) const { return DmaLane{kOOB, 0u, 0, 0}; }
+    __device__ __forceinline__ float4 get(int m0, int kb, int kend, int slot) const
+    {
+        const int m = m0 + 4 * (slot & 3), k = kb + (slot >> 2);
+        const float* q = Y ? Y + (long)min(k, max(kend - 1, 0)) * C : g_zero16;
+        const bool kok = k < kend;
+        const int cm = Y ? C - 1 : 0;
+        float e[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float y = q[min(m + t, cm)];
+            e[t] = (m + t < C) ? (Y ? y : 0.f) : ((m + t == C) ? 1.f : 0.f);
+            e[t] = kok ? e[t] : 0.f;
+        }
+        return make_float4(e[0], e[1], e[2], e[3]);
+    }
+};
 
-// largest panel that fits 160 KiB with 4 waves, multiple of 16
-template <int NT>
-__host__ __device__ constexpr int strip_max_panel() { return (163840 / 4 / ((NT + 1) * 64)) / 16 * 16; }
+// Gradient A operand for the column sums of the B operand: row 0 is all ones, the other rows are zero.
+struct ViewOnesRow {
+    using elem = float;
+    static constexpr bool kK4 = false;
+    __device__ __forceinline__ rsrc_t rsrc() const { return make_rsrc(nullptr, 0); }
+    __device__ __forceinline__ DmaLane lane0(int, int, int) const { return DmaLane{kOOB, 0u, 0, 0}; }
+    __device__ __forceinline__ float4 get(int m0, int kb, int kend, int slot) const
+    {
+        const int m = m0 + 4 * (slot & 3), k = kb + (slot >> 2);
+        return make_float4((k < kend && m == 0) ? 1.f : 0.f, 0.f, 0.f, 0.f);
+    }
+};
+
+// ---- LDS budget ----------------------------------------------------------------------------------
+// bytes of one wave's staging region for panel length KP (multiple of 64): MT A tiles + NT fp32 B tiles,
+// and never smaller than the [16*MT][16*NT+4] fp32 partial strip that later reuses it
+template <int MT, int NT, int ASZ>
+__host__ __device__ constexpr int strip_wave_bytes(int KP)
+{
+    const int stage = MT * 16 * KP * ASZ + NT * 16 * KP * 4;
+    const int red = 16 * MT * (16 * NT + 4) * 4;
+    return stage > red ? stage : red;
+}
+template <int MT, int NT, int ASZ>
+__host__ __device__ constexpr int strip_lds_bytes(int KP) { return 4 * strip_wave_bytes<MT, NT, ASZ>(KP); }
+
+// largest panel (multiple of 64) that fits 160 KiB with 4 waves and keeps the DMA count under vm_wait's range
+template <int MT, int NT, int ASZ>
+__host__ __device__ constexpr int strip_max_panel()
+{
+    int kp = (163840 / 4) / (MT * 16 * ASZ + NT * 16 * 4) / 64 * 64;
+    const int per16 = (ASZ == 4 ? MT : 0) + NT;                     // DMA instructions per piece (u8 A: MT per 4 pieces)
+    while (kp > 64 && (kp / 16) * per16 + (ASZ == 1 ? MT * (kp / 64) : 0) > 60) kp -= 64;
+    return kp;
+}
 
 struct StripOut {
     float4 sum;  // ((q0+q1)+q2)+q3 for columns n0+4*cg .. +3 of row m0+row
-    int row;     // 0..15
+    int row;     // 0..16*MT-1
     int cg;      // 0..4*NT-1
     bool valid;  // this thread holds an output
 };
@@ -190,108 +287,187 @@ __device__ __forceinline__ void vm_wait(int n)
 #undef QBM_VMW
 }
 
-// A_K4 / B_K4: the operand's K index is the contiguous one (k4 image), else lin image.
-//   A_K4: A.get(row, k, kend)   else A.get(k, m, kend)
-//   B_K4: B.get(col, k, kend)   else B.get(k, n, kend)
-template <int NT, bool A_K4, bool B_K4, class AView, class BView>
+// KP: panel length, multiple of 64.  lds: the workgroup's dynamic LDS (strip_lds_bytes<MT,NT,sizeof(elem)>(KP)).
+// FAST: both operands are staged by LDS-DMA (the host guarantees alignment and whole 16-byte units);
+// otherwise values go through registers (any shape, any alignment).
+template <int MT, int NT, bool FAST, class AView, class BView>
 __device__ __forceinline__ StripOut strip_mma(const AView& A, const BView& Bv, int m0, int n0, int K,
-                                              float* __restrict__ lds, int KP)
+                                              char* __restrict__ lds, int KP)
 {
+    using TA = typename AView::elem;
+    constexpr bool A8 = sizeof(TA) == 1;
+    constexpr bool A_K4 = AView::kK4, B_K4 = BView::kK4;
+    constexpr int ASZ = (int)sizeof(TA);
+    static_assert(sizeof(typename BView::elem) == 4, "the B operand is fp32");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave id == K quarter (wave-uniform, SGPR)
     const int Kq = quarter_len(K);
     const int kq0 = q * Kq;
     const int kend = min(K, kq0 + Kq);
-    float* img = lds + (size_t)q * (NT + 1) * 16 * KP;
+    const int wave_bytes = strip_wave_bytes<MT, NT, ASZ>(KP);
+    char* img = lds + (size_t)q * wave_bytes;
+    char* imgA = img;                              // MT tiles of 16*KP*ASZ bytes
+    char* imgB = img + (size_t)MT * 16 * KP * ASZ;  // NT tiles of 16*KP*4 bytes
+    const int a_tile = 16 * KP * ASZ, b_tile = 16 * KP * 4;
 
-    f32x4 acc[NT];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    QBM_STAMP(0);
 
-    const bool dmaA = A.dma(m0, 16, K), dmaB = Bv.dma(n0, 16 * NT, K);  // workgroup-uniform
-    const int fragA = A_K4 ? ((lane & 15) * 4 + (lane >> 4)) : lane;
-    const int fragB = B_K4 ? ((lane & 15) * 4 + (lane >> 4)) : lane;
+    const int fragB = (B_K4 ? ((lane & 15) * 4 + (lane >> 4)) : lane) * 4;                  // byte offset in a piece
+    const int fragA = A8 ? (A_K4 ? (lane & 15) * 16 : (lane >> 4) * 16 + (lane & 15))       // u8: see header
+                         : (A_K4 ? ((lane & 15) * 4 + (lane >> 4)) : lane) * 4;
+    const int shA = 8 * (lane >> 4);  // u8 k4: byte (lane>>4) of each dword
+
+    // fragments of one piece (4 k-steps): LDS -> registers, u8 widened to fp32
+    auto frag = [&](int pc, float (&fa)[MT][4], float (&fb)[NT][4]) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const char* ia = imgA + i * a_tile;
+            if constexpr (A8) {
+                if constexpr (A_K4) {
+                    const uint4 d = *reinterpret_cast<const uint4*>(ia + pc * 256 + fragA);
+                    fa[i][0] = (float)((d.x >> shA) & 255u); fa[i][1] = (float)((d.y >> shA) & 255u);
+                    fa[i][2] = (float)((d.z >> shA) & 255u); fa[i][3] = (float)((d.w >> shA) & 255u);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) fa[i][s] = (float)*reinterpret_cast<const uint8_t*>(ia + pc * 256 + s * 64 + fragA);
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) fa[i][s] = *reinterpret_cast<const float*>(ia + pc * 1024 + s * 256 + fragA);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) fb[t][s] = *reinterpret_cast<const float*>(imgB + t * b_tile + pc * 1024 + s * 256 + fragB);
+    };
+    auto mma = [&](const float (&fa)[MT][4], const float (&fb)[NT][4]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][s], fb[t][s], acc[i][t], 0, 0, 0);
+    };
+    // MFMA over pieces [p0, p1): the fragments of piece pc+1 are read while the MFMAs of piece pc issue.
+    // No asm and no barrier inside, so that the compiler software-pipelines the ds_reads under the MFMAs.
+    auto run = [&](int p0, int p1) {
+        float a0[MT][4], b0[NT][4], a1[MT][4], b1[NT][4];
+        if (p0 < p1) frag(p0, a0, b0);
+        int pc = p0;
+        for (; pc + 1 < p1; pc += 2) {
+            frag(pc + 1, a1, b1);
+            mma(a0, b0);
+            if (pc + 2 < p1) frag(pc + 2, a0, b0);
+            mma(a1, b1);
+        }
+        if (pc < p1) mma(a0, b0);
+    };
 
     for (int kb = kq0; kb < kq0 + Kq; kb += KP) {
         const int klen = max(0, min(kend - kb, KP));
-        const int pieces = (klen + 15) >> 4;  // 16 k per piece = 1 KiB per image = one LDS-DMA instruction
-        // ---- stage: every piece of this wave's K range is issued before anything is waited for.
-        // Issue order is piece-major (A, B_0.. of piece 0, then piece 1, ...) so that a counted vmcnt
-        // releases the pieces in the order the MFMA loop consumes them.
-        for (int pc = 0; pc < pieces; ++pc) {
-            const int slot = pc * 64 + lane;
-            if (dmaA) {
-                const float* g = A_K4 ? A.addr(m0 + (slot & 15), kb + 4 * (slot >> 4), kend)
-                                      : A.addr(kb + (slot >> 2), m0 + 4 * (slot & 3), kend);
-                glds16(g, img + pc * 256);
-            } else {
-                float4 va;
-                if (A_K4) va = A.get(m0 + (slot & 15), kb + 4 * (slot >> 4), kend);
-                else      va = A.get(kb + (slot >> 2), m0 + 4 * (slot & 3), kend);
-                reinterpret_cast<float4*>(img)[slot] = va;
-            }
+        const int pieces = (klen + 15) >> 4;   // 16 k per piece (klen is a multiple of 16 on the FAST path)
+        if constexpr (FAST) {
+            // ---- LDS-DMA: every instruction of this wave's K range is issued before anything is waited for.
+            // Issue order: per piece [A tiles (u8: once per 4 pieces), B tiles].
+            const rsrc_t ra = A.rsrc(), rb = Bv.rsrc();
+            DmaLane la[MT], lb[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                float* imgB = img + (size_t)(1 + t) * 16 * KP;
-                if (dmaB) {
-                    const float* g = B_K4 ? Bv.addr(n0 + 16 * t + (slot & 15), kb + 4 * (slot >> 4), kend)
-                                          : Bv.addr(kb + (slot >> 2), n0 + 16 * t + 4 * (slot & 3), kend);
-                    glds16(g, imgB + pc * 256);
-                } else {
-                    float4 vb;
-                    if (B_K4) vb = Bv.get(n0 + 16 * t + (slot & 15), kb + 4 * (slot >> 4), kend);
-                    else      vb = Bv.get(kb + (slot >> 2), n0 + 16 * t + 4 * (slot & 3), kend);
-                    reinterpret_cast<float4*>(imgB)[slot] = vb;
+            for (int i = 0; i < MT; ++i) la[i] = A.lane0(m0 + 16 * i, kb, lane);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) lb[t] = Bv.lane0(n0 + 16 * t, kb, lane);
+            const int half = (pieces + 1) >> 1;
+            int issued_half = 0, issued = 0;
+            for (int pc = 0; pc < pieces; ++pc) {
+                if (!A8 || (pc & 3) == 0) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        // u8: one instruction covers 4 pieces; lanes past the end of the K quarter read zeros
+                        const unsigned off = (!A8 || la[i].k < kend) ? la[i].voff : kOOB;
+                        blds16(ra, off, imgA + i * a_tile + (A8 ? (pc >> 2) : pc) * 1024);
+                        la[i].voff += la[i].step;
+                        la[i].k += la[i].kstep;
+                    }
+                    issued += MT;
                 }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    blds16(rb, lb[t].voff, imgB + t * b_tile + pc * 1024);
+                    lb[t].voff += lb[t].step;
+                }
+                issued += NT;
+                if (pc == half - 1) issued_half = issued;
             }
-        }
-        const bool counted = dmaA && dmaB;  // pure LDS-DMA staging: release piece by piece
-        if (!counted) vm_wait(0);
-        // ---- contract: one piece = 4 MFMA k-steps per accumulator; out-of-range k was staged as zeros.
-        // The staged data is wave-private, so no workgroup barrier is needed here.
-        for (int pc = 0; pc < pieces; ++pc) {
-            if (counted) vm_wait((pieces - 1 - pc) * (NT + 1));
-            float a[4], b[NT][4];
+            QBM_STAMP(1);
+            // The compiler does not order a ds_read behind a pending LDS-DMA: the two halves of the MFMA
+            // loop sit behind explicit vmcnt waits (counted for the first half, so that the second half of
+            // the transfers lands under the first half of the MFMAs).
+            if (QBM_DIAG_MODE == 1) vm_wait(0); else vm_wait(issued - issued_half);
+            QBM_STAMP(2);
+            if (QBM_DIAG_MODE != 3) run(0, half);
+            vm_wait(0);
+            if (QBM_DIAG_MODE != 3) run(half, pieces);
+        } else {
+            // ---- generic path (unaligned / ragged / synthesised operands): values through registers
+            const int quads = (pieces + 3) >> 2;
+            if constexpr (A8) {
+                for (int g = 0; g < quads; ++g)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                a[s] = img[(pc * 4 + s) * 64 + fragA];
+                    for (int i = 0; i < MT; ++i)
+                        reinterpret_cast<uint4*>(imgA + i * a_tile)[g * 64 + lane] = A.get(m0 + 16 * i, kb, kend, g * 64 + lane);
+            } else {
+                for (int pc = 0; pc < pieces; ++pc)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) b[t][s] = img[(size_t)(1 + t) * 16 * KP + (pc * 4 + s) * 64 + fragB];
+                    for (int i = 0; i < MT; ++i)
+                        reinterpret_cast<float4*>(imgA + i * a_tile)[pc * 64 + lane] = A.get(m0 + 16 * i, kb, kend, pc * 64 + lane);
             }
+            for (int pc = 0; pc < pieces; ++pc)
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[t][s], acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t)
+                    reinterpret_cast<float4*>(imgB + t * b_tile)[pc * 64 + lane] = Bv.get(n0 + 16 * t, kb, kend, pc * 64 + lane);
+            QBM_STAMP(1);
+            QBM_STAMP(2);
+            run(0, pieces);
         }
+        QBM_STAMP(3);
     }
 
     // partial strips -> LDS (each wave reuses the head of its own staging region), row-major
-    // [16][RS], RS = 16*NT + 4 (the +4 keeps lanes l and l+16, four rows apart, on different banks)
+    // [16*MT][RS], RS = 16*NT + 4 (the +4 keeps lanes l and l+16, four rows apart, on different banks)
     constexpr int RS = 16 * NT + 4;
+    float* red = reinterpret_cast<float*>(img);
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) img[((lane >> 4) * 4 + r) * RS + 16 * t + (lane & 15)] = acc[t][r];
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(16 * i + (lane >> 4) * 4 + r) * RS + 16 * t + (lane & 15)] = acc[i][t][r];
     __syncthreads();
 
     StripOut o;
-    o.valid = tid < 64 * NT;
+    o.valid = tid < 64 * MT * NT;
     o.row = tid / (4 * NT);
     o.cg = tid % (4 * NT);
     o.sum = make_float4(0.f, 0.f, 0.f, 0.f);
     if (o.valid) {
-        const size_t wstride = (size_t)(NT + 1) * 16 * KP;
-        const float* base = lds + o.row * RS + 4 * o.cg;
+        const char* base = lds + (size_t)(o.row * RS + 4 * o.cg) * 4;
         const float4 p0 = *reinterpret_cast<const float4*>(base);
-        const float4 p1 = *reinterpret_cast<const float4*>(base + wstride);
-        const float4 p2 = *reinterpret_cast<const float4*>(base + 2 * wstride);
-        const float4 p3 = *reinterpret_cast<const float4*>(base + 3 * wstride);
+        const float4 p1 = *reinterpret_cast<const float4*>(base + wave_bytes);
+        const float4 p2 = *reinterpret_cast<const float4*>(base + 2 * (size_t)wave_bytes);
+        const float4 p3 = *reinterpret_cast<const float4*>(base + 3 * (size_t)wave_bytes);
         o.sum.x = ((p0.x + p1.x) + p2.x) + p3.x;
         o.sum.y = ((p0.y + p1.y) + p2.y) + p3.y;
         o.sum.z = ((p0.z + p1.z) + p2.z) + p3.z;
         o.sum.w = ((p0.w + p1.w) + p2.w) + p3.w;
     }
+    QBM_STAMP(4);
     __syncthreads();  // the partials are consumed: the caller may run another contraction on this LDS
     return o;
 }

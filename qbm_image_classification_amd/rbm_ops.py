@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import CdWorkspace, DiscWorkspace, RbmGrads, RbmParams, check, current_stream, ptr
+from ._lib import QBM_F32, QBM_U8, CdWorkspace, DiscWorkspace, RbmGrads, RbmParams, check, current_stream, ptr
 
 
 class ParamSet:
@@ -56,6 +56,16 @@ def _f32(t, device):
     if t.dtype != torch.float32 or t.device != device or not t.is_contiguous():
         t = t.to(device=device, dtype=torch.float32).contiguous()
     return t
+
+
+def _state(t, device):
+    """A Gibbs-state tensor for the *_ex entry points: uint8 stays uint8, everything else becomes fp32."""
+    t = torch.as_tensor(t)
+    if t.dtype == torch.uint8:
+        if t.device != device or not t.is_contiguous():
+            t = t.to(device).contiguous()
+        return t, QBM_U8
+    return _f32(t, device), QBM_F32
 
 
 class HipRbmOps:
@@ -110,6 +120,43 @@ class HipRbmOps:
                                             current_stream()), "qbm_rbm_sample_class")
         return p, s
 
+    def sample_hidden_ex(self, P: ParamSet, v, y=None, seed=0, offset=0, row0=0, want_p=True, want_s=False,
+                         want_s8=True):
+        """v may be uint8 {0,1}; the sample can come back as fp32 and/or uint8. -> (p, s_f32, s_u8)"""
+        v, vd = _state(v, self.device)
+        y = None if y is None else _f32(y, self.device)
+        B = v.shape[0]
+        p = torch.empty(B, P.H, dtype=torch.float32, device=self.device) if want_p else None
+        s = torch.empty(B, P.H, dtype=torch.float32, device=self.device) if want_s else None
+        s8 = torch.empty(B, P.H, dtype=torch.uint8, device=self.device) if want_s8 else None
+        ps = P.struct()
+        check(self.lib.qbm_rbm_sample_hidden_ex(C.byref(ps), ptr(v), vd, ptr(y), B, ptr(p), ptr(s), ptr(s8), seed,
+                                                offset, row0, current_stream()), "qbm_rbm_sample_hidden_ex")
+        return p, s, s8
+
+    def sample_visible_class(self, P: ParamSet, h, seed=0, offset_v=0, offset_y=1, row0=0, want_p=False, want_s=False,
+                             want_s8=True, want_py=False, want_y=True):
+        """One launch for v ~ p(v|h) and y ~ p(y|h). -> (p_v, v_f32, v_u8, p_y, y1hot)"""
+        h, hd = _state(h, self.device)
+        B = h.shape[0]
+        f = lambda n, dt: torch.empty(B, n, dtype=dt, device=self.device)
+        pv = f(P.V, torch.float32) if want_p else None
+        vs = f(P.V, torch.float32) if want_s else None
+        v8 = f(P.V, torch.uint8) if want_s8 else None
+        py = f(P.C, torch.float32) if want_py else None
+        ys = f(P.C, torch.float32) if want_y else None
+        ps = P.struct()
+        check(self.lib.qbm_rbm_sample_visible_class_ex(C.byref(ps), ptr(h), hd, B, ptr(pv), ptr(vs), ptr(v8), ptr(py),
+                                                       ptr(ys), seed, offset_v, offset_y, row0, current_stream()),
+              "qbm_rbm_sample_visible_class_ex")
+        return pv, vs, v8, py, ys
+
+    def to_u8(self, x):
+        x = _f32(x, self.device)
+        y = torch.empty(x.shape, dtype=torch.uint8, device=self.device)
+        check(self.lib.qbm_f32_to_u8(ptr(x), ptr(y), x.numel(), current_stream()), "qbm_f32_to_u8")
+        return y
+
     def free_energy(self, P: ParamSet, x):
         """-> (-F [B,C], p(y|x) [B,C])"""
         x = _f32(x, self.device)
@@ -139,21 +186,27 @@ class HipRbmOps:
 
     def cd_step(self, P: ParamSet, G: GradSet, v0, y0, k, seed, offset, row0, chain_v, chain_y, fuse, lr, factor,
                 batch_size, sparse, ws=None):
-        """CD-k / PCD step: chain + gradient (+ fused update when `fuse`)."""
-        v0, y0 = _f32(v0, self.device), _f32(y0, self.device)
+        """CD-k / PCD step: chain + gradient (+ fused update when `fuse`).
+        v0: fp32 or uint8 {0,1} [B,V]; chain_v: uint8 [B,V] persistent state (PCD) or None.
+        -> workspace (ph0 f32, h u8, vk u8, yk f32, phk f32)"""
+        v0, vd = _state(v0, self.device)
+        y0 = _f32(y0, self.device)
         B = v0.shape[0]
+        if chain_v is not None and chain_v.dtype != torch.uint8:
+            raise _lib.QbmHipError("persistent chain state must be uint8")
         if ws is None:
             ws = self.cd_workspace(P, B)
         cws = CdWorkspace(*(ptr(t) for t in ws))
         ps, gs = P.struct(), G.struct()
-        check(self.lib.qbm_rbm_cd_step(C.byref(ps), C.byref(gs), ptr(v0), ptr(y0), B, k, seed, offset, row0,
+        check(self.lib.qbm_rbm_cd_step(C.byref(ps), C.byref(gs), ptr(v0), vd, ptr(y0), B, k, seed, offset, row0,
                                        ptr(chain_v), ptr(chain_y), C.byref(cws), int(fuse), lr, factor, batch_size,
                                        sparse, current_stream()), "qbm_rbm_cd_step")
         return ws
 
     def cd_workspace(self, P: ParamSet, B):
-        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.device)
-        return (f(B, P.H), f(B, P.H), f(B, P.V), f(B, P.C), f(B, P.H))  # ph0, h, vk, yk, phk
+        f = lambda n, dt: torch.empty(B, n, dtype=dt, device=self.device)
+        return (f(P.H, torch.float32), f(P.H, torch.uint8), f(P.V, torch.uint8), f(P.C, torch.float32),
+                f(P.H, torch.float32))  # ph0, h, vk, yk, phk
 
     def update(self, P: ParamSet, G: GradSet, lr, factor, batch_size, sparse, with_gb=True):
         ps, gs = P.struct(), G.struct(with_gb=with_gb)
@@ -161,9 +214,11 @@ class HipRbmOps:
               "qbm_rbm_update")
 
     def two_phase_grad(self, V, H, Cn, A0, Y0, P0, A1, Y1, P1, G: GradSet):
+        A0, d0 = _state(A0, self.device)
+        A1, d1 = _state(A1, self.device)
         B = A0.shape[0]
         gs = G.struct()
-        check(self.lib.qbm_rbm_two_phase_grad(V, H, Cn, B, ptr(A0), ptr(Y0), ptr(P0), ptr(A1), ptr(Y1), ptr(P1),
+        check(self.lib.qbm_rbm_two_phase_grad(V, H, Cn, B, ptr(A0), d0, ptr(Y0), ptr(P0), ptr(A1), d1, ptr(Y1), ptr(P1),
                                               C.byref(gs), None, None, 0.0, 0.0, 1.0, 0.0, current_stream()),
               "qbm_rbm_two_phase_grad")
 

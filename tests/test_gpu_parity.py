@@ -95,6 +95,20 @@ def test_conditionals_bitwise(ops, oracle, V, H, C, B):
     assert_bitwise(p, po, "p(y|h)")
     assert_bitwise(s, so, "y sample")
     assert (s.sum(1) == 1).all()
+    # uint8 {0,1} states in, fp32 + uint8 samples out: identical bits to the fp32 path
+    ph_o, sh_o = oracle.rbm_sample_hidden(v_bin, y1h, W, d, U, seed, off, row0)
+    p8, sf, s8 = ops.sample_hidden_ex(P, dev(ops, v_bin.astype(np.uint8)), dev(ops, y1h), seed, off, row0, True, True, True)
+    assert_bitwise(p8, ph_o, "p(h|v u8,y)")
+    assert_bitwise(sf, sh_o, "h sample (u8 input)")
+    assert np.array_equal(s8.cpu().numpy(), sh_o.astype(np.uint8))
+    pv_o, sv_o = oracle.rbm_sample_visible(h_bin, W, b, seed, off + 1, row0)
+    pv, vf, v8, py, ys = ops.sample_visible_class(P, dev(ops, h_bin.astype(np.uint8)), seed, off + 1, off + 2, row0,
+                                                  True, True, True, True, True)
+    assert_bitwise(pv, pv_o, "p(v|h u8)")
+    assert_bitwise(vf, sv_o, "v sample (u8 input)")
+    assert np.array_equal(v8.cpu().numpy(), sv_o.astype(np.uint8))
+    assert_bitwise(py, po, "p(y|h u8) riding along")
+    assert_bitwise(ys, so, "y sample riding along")
 
 
 @pytest.mark.parametrize("V,H,C,B", SHAPES)
@@ -166,16 +180,18 @@ def test_cd_step_bitwise(ops, oracle, V, H, C, B, k, pcd):
     for fuse in (False, True):
         P = P_of(ops, W, b, d, U, c)
         G = GradSet(V, H, C, ops.device)
-        chain_v = dev(ops, np.roll(v_bin, 1, axis=0)) if pcd else None
+        chain_v = dev(ops, np.roll(v_bin, 1, axis=0).astype(np.uint8)) if pcd else None
         chain_y = dev(ops, np.roll(y1h, 1, axis=0)) if pcd else None
-        ws = ops.cd_step(P, G, dev(ops, v_bin), dev(ops, y1h), k, seed, off, row0, chain_v, chain_y, fuse, 0.05, 1.0,
+        # the visible data go in as fp32 (what the reference holds) or as uint8 {0,1}: same bits out
+        v0_in = dev(ops, v_bin) if not fuse else dev(ops, v_bin.astype(np.uint8))
+        ws = ops.cd_step(P, G, v0_in, dev(ops, y1h), k, seed, off, row0, chain_v, chain_y, fuse, 0.05, 1.0,
                          float(B), 0.0)
         assert_bitwise(ws[0], ph0, "p(h0)")
-        assert_bitwise(ws[2], vk, "v_k")
+        assert np.array_equal(ws[2].cpu().numpy(), vk.astype(np.uint8)), "v_k"
         assert_bitwise(ws[3], yk, "y_k")
         assert_bitwise(ws[4], phk, "p(h_k)")
         if pcd:
-            assert_bitwise(chain_v, cv[0], "persistent v")
+            assert np.array_equal(chain_v.cpu().numpy(), cv[0].astype(np.uint8)), "persistent v"
             assert_bitwise(chain_y, cv[1], "persistent y")
         if not fuse:
             assert_bitwise(G.gW, gW, "gW")

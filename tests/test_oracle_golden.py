@@ -48,11 +48,11 @@ def test_det_math_accuracy(oracle):
 
 def test_qgemm_is_quartered_fma_chain(oracle):
     rs = np.random.RandomState(0)
-    for (M, N, K) in [(3, 5, 16), (2, 4, 9), (4, 3, 784), (1, 2, 1), (2, 2, 5)]:
+    for (M, N, K) in [(3, 5, 16), (2, 4, 9), (4, 3, 784), (1, 2, 1), (2, 2, 5), (2, 3, 100)]:
         A = rs.standard_normal((M, K)).astype(np.float32)
         B = rs.standard_normal((K, N)).astype(np.float32)
         got = oracle.qgemm(A, B)
-        Kq = ((K + 3) // 4 + 3) // 4 * 4
+        Kq = ((K + 3) // 4 + 15) // 16 * 16
         want = np.zeros((M, N), np.float32)
         for m in range(M):
             for n in range(N):
