@@ -201,11 +201,19 @@ QBM_API int qbm_rbm_disc_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, c
  *   whole batch;  R reads (independent chains) per image;  `sweeps` sequential heat-bath sweeps with a
  *   geometric inverse-temperature schedule beta0 -> beta1 (beta0 == beta1: plain Gibbs sampling).
  * Outputs: states[B,R,n] uint8 in {0,1} (column j = variable j, the reference's sample order) and,
- * if non-NULL, mean[B,n] = average over reads (np.average(np_samples, axis=0), faster_dqbm.py:780).
+ * if non-NULL, mean[B,n] float64 = average over reads (np.average(np_samples, axis=0), faster_dqbm.py:780).
  * Draw ids: start state -> offset, sweep t -> offset + t; Philox row = b*R + r, col = variable. */
 QBM_API int qbm_qubo_gibbs(const float* lin, const float* J, int B, int R, int n, int sweeps, float beta0,
-                           float beta1, uint64_t seed, uint64_t offset, uint8_t* states, float* mean,
+                           float beta1, uint64_t seed, uint64_t offset, uint8_t* states, double* mean,
                            void* stream);
+
+/* Disc_QBM.get_average_configuration_batch, src/model/faster_dqbm.py:754-848, from the per-image means over
+ * reads (float64, images accumulated in order).  labels != NULL = clamped phase (mean[B,H]), NULL = unclamped
+ * (mean[B,1+H], variable 0 = output node).  Outputs (overwritten): W_vh[(1+D),H] with the reference's
+ * statistics layout (rows 0..D-1 pixels, row D label: SURVEY.md Appendix A Q7), W_vo[D], b_h[H], b_o[1].
+ * W_oo and W_hh statistics are identically zero in the reference (Q8) and are not produced. */
+QBM_API int qbm_qbm_batch_stats(const double* X, const int32_t* labels, const double* mean, int B, int D, int H,
+                                double* W_vh, double* W_vo, double* b_h, double* b_o, void* stream);
 
 /* x-dependent part of Disc_QBM.create_qubo_matrix_from (src/model/faster_dqbm.py:225-284), float64:
  *   labels != NULL (clamped, n = H):   lin_j = (b_h[j] + label*W_vh[0,j] + sum_k x_k W_vh[1+k,j]) / beta_eff

@@ -261,14 +261,31 @@ def qbm_couplings(W_vh, W_hh, clamped: bool, beta_eff=1.0):
 
 
 def qubo_gibbs(lin, J, reads, sweeps, beta0=1.0, beta1=1.0, seed=0, offset=0):
-    """-> (states u8 [B,R,n], mean f32 [B,n])"""
+    """-> (states u8 [B,R,n], mean f64 [B,n])"""
     lin, J = _f32(lin), _f32(J)
     B, n = lin.shape
     states = np.empty((B, reads, n), np.uint8)
-    mean = np.empty((B, n), np.float32)
+    mean = np.empty((B, n), np.float64)
     f = lib().orc_qubo_gibbs
     f.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_uint64,
-                  _u8p, _f32p]
+                  _u8p, _f64p]
     f.restype = None
     f(lin, J, B, reads, n, sweeps, beta0, beta1, seed, offset, states, mean)
     return states, mean
+
+
+def qbm_batch_stats(X, labels, mean, H):
+    """get_average_configuration_batch from per-image means -> (W_vh [(1+D),H], W_vo [D], b_h [H], b_o [1]) f64"""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    mean = np.ascontiguousarray(mean, dtype=np.float64)
+    B, D = X.shape
+    lab = None if labels is None else np.ascontiguousarray(labels, dtype=np.int32)
+    W_vh = np.empty((1 + D, H), np.float64)
+    W_vo = np.empty(D, np.float64)
+    b_h = np.empty(H, np.float64)
+    b_o = np.empty(1, np.float64)
+    f = lib().orc_qbm_batch_stats
+    f.argtypes = [_f64p, C.c_void_p, _f64p, C.c_int, C.c_int, C.c_int, _f64p, _f64p, _f64p, _f64p]
+    f.restype = None
+    f(X, _opt(lab), mean, B, D, H, W_vh, W_vo, b_h, b_o)
+    return W_vh, W_vo, b_h, b_o

@@ -65,6 +65,7 @@ SIGNATURES = {
     "qbm_test_math": [_i, _p, _p, _i, _p],
     "qbm_test_uniform": [_u64, _u64, _u32, _i, _i, _p, _p],
     "qbm_qubo_gibbs": [_p, _p, _i, _i, _i, _i, _f, _f, _u64, _u64, _p, _p, _p],
+    "qbm_qbm_batch_stats": [_p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p],
     "qbm_qbm_linear_fields": [_p, _p, _p, _p, _p, C.c_double, _i, _i, _i, C.c_double, _p, _p],
 }
 

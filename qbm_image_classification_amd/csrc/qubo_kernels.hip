@@ -102,17 +102,55 @@ __global__ __launch_bounds__(256) void k_qubo_gibbs(const float* __restrict__ li
     }
 }
 
-// mean over reads: sequential fp32 sum over r, divided by R
-// (np.average(np_samples, axis=0), src/model/faster_dqbm.py:780)
-__global__ __launch_bounds__(256) void k_read_mean(const uint8_t* __restrict__ states, float* __restrict__ mean,
+// mean over reads, float64: exact count / R  (np.average(np_samples, axis=0) on {0,1} samples,
+// src/model/faster_dqbm.py:780)
+__global__ __launch_bounds__(256) void k_read_mean(const uint8_t* __restrict__ states, double* __restrict__ mean,
                                                    int B, int R, int n)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * n) return;
     const int b = idx / n, i = idx % n;
-    float a = 0.f;
-    for (int r = 0; r < R; ++r) a = a + (float)states[((long)b * R + r) * n + i];
-    mean[idx] = a / (float)R;
+    int cnt = 0;
+    for (int r = 0; r < R; ++r) cnt += states[((long)b * R + r) * n + i];
+    mean[idx] = (double)cnt / (double)R;
+}
+
+// get_average_configuration_batch (src/model/faster_dqbm.py:754-848) from the per-image means: float64,
+// sequential over the images, product then sum.  One thread per output element:
+//   idx <  (1+D)*H          : W_vh[k][j]   (k < D: pixel rows; k == D: the label row, clamped phase only)
+//   idx <  (1+D)*H + D      : W_vo[k]
+//   idx <  (1+D)*H + D + H  : b_h[j]
+//   last                    : b_o
+__global__ __launch_bounds__(256) void k_batch_stats(const double* __restrict__ X, const int* __restrict__ labels,
+                                                     const double* __restrict__ mean, int B, int D, int H,
+                                                     double* __restrict__ W_vh, double* __restrict__ W_vo,
+                                                     double* __restrict__ b_h, double* __restrict__ b_o)
+{
+    const int n = labels ? H : H + 1, o = labels ? 0 : 1;
+    const long nW = (long)(1 + D) * H;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nW + D + H + 1) return;
+    double acc = 0.0;
+    if (idx < nW) {
+        const int k = (int)(idx / H), j = (int)(idx % H);
+        if (k < D) {
+            for (int i = 0; i < B; ++i) acc += X[(long)i * D + k] * mean[(long)i * n + o + j];
+        } else if (labels) {
+            for (int i = 0; i < B; ++i) acc += (double)labels[i] * mean[(long)i * n + o + j];
+        }
+        W_vh[idx] = acc;
+    } else if (idx < nW + D) {
+        const int k = (int)(idx - nW);
+        for (int i = 0; i < B; ++i) acc += X[(long)i * D + k] * (labels ? (double)labels[i] : mean[(long)i * n]);
+        W_vo[k] = acc;
+    } else if (idx < nW + D + H) {
+        const int j = (int)(idx - nW - D);
+        for (int i = 0; i < B; ++i) acc += mean[(long)i * n + o + j];
+        b_h[j] = acc;
+    } else {
+        for (int i = 0; i < B; ++i) acc += labels ? (double)labels[i] : mean[(long)i * n];
+        b_o[0] = acc;
+    }
 }
 
 // x-dependent part of create_qubo_matrix_from (src/model/faster_dqbm.py:236-245, 273-283): float64,
@@ -155,7 +193,7 @@ int launch_gibbs(const float* lin, const float* J, int B, int R, int n, int swee
 extern "C" {
 
 int qbm_qubo_gibbs(const float* lin, const float* J, int B, int R, int n, int sweeps, float beta0, float beta1,
-                   uint64_t seed, uint64_t offset, uint8_t* states, float* mean, void* stream)
+                   uint64_t seed, uint64_t offset, uint8_t* states, double* mean, void* stream)
 {
     if (B < 0 || R < 0) return fail(QBM_ERR_ARG, "qubo_gibbs: negative batch/reads");
     if (B == 0 || R == 0) return QBM_OK;
@@ -181,6 +219,19 @@ int qbm_qubo_gibbs(const float* lin, const float* J, int B, int R, int n, int sw
         hipLaunchKernelGGL(k_read_mean, dim3((B * n + 255) / 256), dim3(256), 0, st, states, mean, B, R, n);
         QBM_CHECK_LAUNCH("k_read_mean");
     }
+    return QBM_OK;
+}
+
+int qbm_qbm_batch_stats(const double* X, const int32_t* labels, const double* mean, int B, int D, int H, double* W_vh,
+                        double* W_vo, double* b_h, double* b_o, void* stream)
+{
+    if (B < 0) return fail(QBM_ERR_ARG, "batch_stats: B < 0");
+    if (D <= 0 || H <= 0) return fail(QBM_ERR_ARG, "batch_stats: non-positive dims");
+    if (!W_vh || !W_vo || !b_h || !b_o || (B > 0 && (!X || !mean))) return fail(QBM_ERR_ARG, "batch_stats: null buffer");
+    const long total = (long)(1 + D) * H + D + H + 1;
+    hipLaunchKernelGGL(k_batch_stats, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, labels,
+                       mean, B, D, H, W_vh, W_vo, b_h, b_o);
+    QBM_CHECK_LAUNCH("k_batch_stats");
     return QBM_OK;
 }
 

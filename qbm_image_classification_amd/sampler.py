@@ -26,14 +26,15 @@ class HipQuboOps:
         self.device = torch.device(device)
 
     def gibbs(self, lin, J, reads, sweeps, beta0=1.0, beta1=1.0, seed=0, offset=0, want_mean=True):
-        """lin [B,n] f32, J [n,n] f32 symmetric zero-diagonal (device tensors) -> (states u8 [B,R,n], mean [B,n])"""
+        """lin [B,n] f32, J [n,n] f32 symmetric zero-diagonal (device tensors)
+        -> (states u8 [B,R,n], mean f64 [B,n])"""
         lin = lin.to(self.device, torch.float32).contiguous()
         J = J.to(self.device, torch.float32).contiguous()
         B, n = lin.shape
         if J.shape != (n, n):
             raise _lib.QbmHipError(f"J must be [{n},{n}], got {tuple(J.shape)}")
         states = torch.empty(B, reads, n, dtype=torch.uint8, device=self.device)
-        mean = torch.empty(B, n, dtype=torch.float32, device=self.device) if want_mean else None
+        mean = torch.empty(B, n, dtype=torch.float64, device=self.device) if want_mean else None
         check(self.lib.qbm_qubo_gibbs(ptr(lin), ptr(J), B, reads, n, sweeps, beta0, beta1, seed, offset, ptr(states),
                                       ptr(mean), current_stream()), "qbm_qubo_gibbs")
         return states, mean
@@ -58,14 +59,45 @@ class HipQuboOps:
         return lin
 
 
+    def batch_stats(self, X, labels, mean, H):
+        """get_average_configuration_batch (faster_dqbm.py:754-848) from per-image means (device, f64).
+        -> (W_vh [(1+D),H], W_vo [D], b_h [H], b_o [1]) float64 device tensors"""
+        X = X.to(self.device, torch.float64).contiguous()
+        mean = mean.to(self.device, torch.float64).contiguous()
+        B, D = X.shape
+        lab = None if labels is None else torch.as_tensor(np.asarray(labels)).to(self.device, torch.int32).contiguous()
+        f = lambda *s: torch.empty(*s, dtype=torch.float64, device=self.device)
+        W_vh, W_vo, b_h, b_o = f(1 + D, H), f(D), f(H), f(1)
+        check(self.lib.qbm_qbm_batch_stats(ptr(X), ptr(lab), ptr(mean), B, D, H, ptr(W_vh), ptr(W_vo), ptr(b_h),
+                                           ptr(b_o), current_stream()), "qbm_qbm_batch_stats")
+        return W_vh, W_vo, b_h, b_o
+
+
+def auto_beta_range(lin: np.ndarray, J: np.ndarray):
+    """Hot/cold inverse temperatures for an annealing schedule, from the spread of single-flip energy
+    changes (the heuristic simulated annealers use: hot = half of the largest flips accepted, cold = the
+    smallest flip accepted 1 time in 100).  lin [B,n] or [n], J [n,n] symmetric, zero diagonal."""
+    lin = np.atleast_2d(np.asarray(lin, dtype=np.float64))
+    J = np.asarray(J, dtype=np.float64)
+    big = np.abs(lin).max(axis=0) + np.abs(J).sum(axis=1)          # largest |dE| a flip of spin i can cause
+    coeffs = np.concatenate([np.abs(lin).ravel(), np.abs(J).ravel()])
+    coeffs = coeffs[coeffs > 0]
+    if coeffs.size == 0 or not np.isfinite(big.max()) or big.max() <= 0:
+        return 0.1, 1.0
+    hot = np.log(2.0) / big.max()
+    cold = np.log(100.0) / coeffs.min()
+    cold = min(max(cold, 10.0 * hot), 1e4 * hot)                     # keep the geometric schedule sane
+    return float(hot), float(cold)
+
+
 class HipGibbsSampler:
     """Drop-in for src/qubo/sampler.py::LocalSASampler (same constructor keywords, same sample_Q)."""
 
-    def __init__(self, num_sweeps: int = 1000, seed: int | None = None, beta_range=(0.1, 4.0), device="cuda:0"):
+    def __init__(self, num_sweeps: int = 1000, seed: int | None = None, beta_range=None, device="cuda:0"):
         self.ops = HipQuboOps(device)
         self.num_sweeps = int(num_sweeps)
         self.seed = 0 if seed is None else int(seed)
-        self.beta_range = (float(beta_range[0]), float(beta_range[1]))
+        self.beta_range = None if beta_range is None else (float(beta_range[0]), float(beta_range[1]))
         self._calls = 0
 
     def sample_Q(self, Q: np.ndarray, num_reads: int) -> np.ndarray:
@@ -78,8 +110,8 @@ class HipGibbsSampler:
         lin = np.diag(Q).astype(np.float32)[None, :]
         off = Q - np.diag(np.diag(Q))
         J = (off + off.T).astype(np.float32)
+        b0, b1 = self.beta_range if self.beta_range is not None else auto_beta_range(lin, J)
         states, _ = self.ops.gibbs(torch.from_numpy(lin), torch.from_numpy(J), int(num_reads), self.num_sweeps,
-                                   self.beta_range[0], self.beta_range[1], self.seed, self._calls << 20,
-                                   want_mean=False)
+                                   b0, b1, self.seed, self._calls << 20, want_mean=False)
         self._calls += 1
         return states[0].to(torch.float32).cpu().numpy()

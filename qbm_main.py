@@ -1,0 +1,113 @@
+#!/usr/bin/env python
+"""qbm_main.py -- drop-in for the reference's qbm_main.py with the QUBO sampler on the GPU (solver "HIP").
+
+Same `main(...)` signature and command line as the reference (qbm_main.py:23-25, :138-216).  Differences: the
+default solver is "HIP" ("SA" is accepted as an alias), `type=bool` flags are parsed as real booleans (the
+reference turns any non-empty string into True), the results are printed and
+pickled by this script instead of the reference's metrics.save_result (which raises AttributeError for
+Disc_QBM, Q12), and datasets are looked up under --data_root (default: the reference layout src/data/...,
+else the committed fixtures under tests/golden/)."""
+import argparse
+import os
+import pickle
+import random
+
+import numpy as np
+
+from qbm_image_classification_amd import data_loader, metrics
+from qbm_image_classification_amd.disc_qbm import Disc_QBM
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _find(root, rel, fixture):
+    for cand in ([os.path.join(root, rel)] if root else []) + [rel, os.path.join(HERE, 'tests/golden', fixture)]:
+        if os.path.exists(cand):
+            return cand
+    raise FileNotFoundError(f'{rel} not found (use --data_root)')
+
+
+def load(data_set, data_root):
+    if data_set == "breastmnist":
+        return data_loader.get_medmnist(_find(data_root, 'src/data/medmnist/breastmnist.npz', 'data_breastmnist.npz'))
+    if data_set == "pneumoniamnist":
+        return data_loader.get_medmnist(_find(data_root, 'src/data/medmnist/pneumoniamnist.npz', 'data_pneumoniamnist.npz'))
+    if data_set == "mnist":
+        # MNIST train images are absent from the reference checkout; the fixture holds the binarised 0/1 test digits
+        f = np.load(os.path.join(HERE, 'tests/golden/data_mnist01_t10k_bits.npz'))
+        x = data_loader.unpack_bits(f['bits'], 784).astype(np.float32).reshape(-1, 28, 28)
+        y = f['labels'].astype(np.uint8)
+        n = int(0.8 * len(x))
+        return (x[:n], y[:n]), (x[n:], y[n:]), (x[n:], y[n:])
+    raise ValueError("Invalid dataset")
+
+
+def main(seed=19, n_hidden_nodes=10, solver="HIP", sample_count=100, anneal=1000, beta_eff=1.0, epochs=3, batch_size=10,
+         learning_rate=0.01, restricted=True, data_set="mnist", num_classes=2, parallelize=False, save="", name="",
+         data_root=None, max_train=None):
+    print("Start")
+    random.seed(seed)
+    np.random.seed(seed)
+    print("Seed is " + str(seed))
+    print("Loading data...")
+    (train_X, train_y), (val_X, val_y), (test_X, test_y) = load(data_set, data_root)
+    print("Data loaded")
+    train_X, test_X, val_X = data_loader.preprocess_images(train_X, test_X, val_X)
+    if max_train:
+        train_X, train_y = train_X[:max_train], train_y[:max_train]
+    param_string = "_se" + str(seed) + "_h" + str(n_hidden_nodes) + "_sol" + solver + "_sc" + str(sample_count) + "_b" + str(
+        beta_eff) + "_e" + str(epochs) + "_bs" + str(batch_size) + "_l" + str(learning_rate) + "_r" + str(restricted) + \
+        "_data" + data_set + "_n_" + name
+    print(param_string)
+    print('Creating QBM...')
+    dqbm = Disc_QBM(seed=seed, epochs=epochs, n_hidden_nodes=n_hidden_nodes, num_classes=num_classes, solver=solver,
+                    sample_count=sample_count, anneal_steps=anneal, beta_eff=beta_eff, restricted=restricted,
+                    param_string=param_string, speicherort=save, dim_input=784, parallelize=parallelize,
+                    use_one_hot_encoding=False)
+    print('QBM created')
+    print('Training QBM...')
+    dqbm.train_model(train_X, train_y, test_X, test_y, batch_size=batch_size, learning_rate=learning_rate)
+    print('QBM trained')
+    print("Predict on test data...")
+    predictions = dqbm.predict_batch(test_X)
+    acc, f1, precision, recall, auc = metrics.get_metrics(np.asarray(test_y), predictions, ["healthy", "pneumonia"])
+    with open((save or "") + name + "acc_auc.pkl", "wb") as f:
+        pickle.dump((acc, auc), f)
+    metrics.save_history((save or "") + name, dqbm.training_history)
+    print("Accuracy: ", acc)
+    print("F1 Score: ", f1)
+    print("Precision: ", precision)
+    print("Recall: ", recall)
+    print("AUC Score: ", auc)
+    return acc, auc
+
+
+def _bool(s):
+    return str(s).lower() in ("1", "true", "yes", "y")
+
+
+if __name__ == '__main__':
+    parser = argparse.ArgumentParser(description='Discriminative QBM with a GPU Gibbs sampler.')
+    parser.add_argument('-hn', '--hnodes', metavar='INT', help='Amount of hidden units for RBM model', default=2, type=int)
+    parser.add_argument('-lr', '--learning_rate', metavar='FLOAT', help='Learning rate for training', default=0.4529451796571889, type=float)
+    parser.add_argument('-r', '--restricted', help='Restricted weights between hidden nodes', default=False, type=_bool)
+    parser.add_argument('-e', '--epochs', metavar='INT', help='Epochs fr training', default=20, type=int)
+    parser.add_argument('-b', '--batch_size', metavar='INT', help='Batchsize for training', default=73, type=int)
+    parser.add_argument('-s', '--seed', metavar='INT', help='Seed for RNG', default=3492574433, type=int)
+    parser.add_argument('-sc', '--sample_count', metavar='INT', help='number of samples to take from the solver', default=100, type=int)
+    parser.add_argument('--solver', help="Solver: 'HIP' (GPU Gibbs / annealing; 'SA' is an alias)", default='HIP', type=str)
+    parser.add_argument('--data_set', help="'mnist', 'breastmnist', 'pneumoniamnist'", default='pneumoniamnist', type=str)
+    parser.add_argument('--num_classes', help='Number of classes in dataset', default=2, type=int)
+    parser.add_argument('--parallelize', help='accepted for compatibility; the GPU path is always batched', default=True, type=_bool)
+    parser.add_argument('--load_path', help='output directory', default="out/", type=str)
+    parser.add_argument('--name', help='Name for run', default="qucun_3492574433", type=str)
+    parser.add_argument('--anneal', help='sweeps per read', default=1000, type=int)
+    parser.add_argument('--data_root', default=None, type=str)
+    parser.add_argument('--max_train', default=None, type=int)
+    flags = parser.parse_args()
+    print("Running with solver", flags.solver)
+    os.makedirs(flags.load_path, exist_ok=True)
+    main(epochs=flags.epochs, n_hidden_nodes=flags.hnodes, learning_rate=flags.learning_rate, batch_size=flags.batch_size,
+         solver=flags.solver, restricted=flags.restricted, seed=flags.seed % (2 ** 32), data_set=flags.data_set,
+         num_classes=flags.num_classes, parallelize=flags.parallelize, sample_count=flags.sample_count, save=flags.load_path,
+         name=flags.name, anneal=flags.anneal, data_root=flags.data_root, max_train=flags.max_train)

@@ -1,0 +1,104 @@
+#!/usr/bin/env python
+"""rbm_main.py -- drop-in for the reference's rbm_main.py on the HIP path.
+
+Same command line (rbm_main.py:12-30 of the reference), same seed list (:32-33), same flow (:36-82):
+load BreastMNIST -> flatten -> ClassificationRBM -> train_rbm -> pickle acc/auc per epoch.  Differences:
+`--type generative|hybrid` work (CD-k / PCD on the GPU; the reference raises NotImplementedError), the
+output directory is created (the reference crashes if it is missing), and the data
+are looked up under --data-root (default: the reference layout src/data/..., else the committed fixture
+tests/golden/data_breastmnist.npz).  Extra flags: --seeds N, --binarise, --persistent, --bars-and-stripes."""
+import argparse
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from qbm_image_classification_amd import data_loader
+from qbm_image_classification_amd.classification_rbm import ClassificationRBM
+
+USE_GPU = True
+
+parser = argparse.ArgumentParser(description='classification_model text classificer')
+parser.add_argument('--lr', type=float, default=0.08714599435919934, help='initial learning rate [default: 0.001]')
+parser.add_argument('--epochs', type=int, default=20, help='number of epochs for train [default: 256]')
+parser.add_argument('--batch-size', type=int, default=7, help='batch size for training [default: 64]')
+parser.add_argument('--early-stop', type=int, default=15, help='iteration numbers to stop without performance increasing')
+parser.add_argument('--visible-units', type=int, default=784, help='Number of dimensions in input')
+parser.add_argument('--hidden-units', type=int, default=9, help='Number of dimensions of the hidden representation')
+parser.add_argument('--no-cuda', action='store_true', default=False, help='disable the gpu')
+parser.add_argument('--cd-k', type=int, default=1, help='The K in the contrastive Divergence Algorithm')
+parser.add_argument('--type', type=str, default='discriminative',
+                    help='The type of training you want to start - discriminative, hybrid and generative')
+parser.add_argument('--sparsity-coeffectient', type=float, default=0.00,
+                    help='The amount that must be subtracted from bias after every update')
+parser.add_argument('--data-folder', type=str, default='data', help='Folder in which the data needs to be stored')
+parser.add_argument('--generative-factor', type=float, default=0.01)
+# build-side extras
+parser.add_argument('--data-root', type=str, default=None, help='directory holding src/data/medmnist/breastmnist.npz')
+parser.add_argument('--seeds', type=int, default=10, help='how many of the 10 reference seeds to run')
+parser.add_argument('--binarise', action='store_true', help='threshold the images at 0.5 ({0,1} visibles)')
+parser.add_argument('--persistent', action='store_true', help='PCD instead of CD-k for generative/hybrid training')
+parser.add_argument('--bars-and-stripes', action='store_true', help='4x4 Bars-and-Stripes instead of BreastMNIST (16 visible units)')
+parser.add_argument('--out-dir', type=str, default='Breast_beta_hyper_RBM')
+
+
+def find_breastmnist(root):
+    here = os.path.dirname(os.path.abspath(__file__))
+    for cand in ([os.path.join(root, 'src/data/medmnist/breastmnist.npz')] if root else []) + [
+            'src/data/medmnist/breastmnist.npz', os.path.join(here, 'tests/golden/data_breastmnist.npz')]:
+        if os.path.exists(cand):
+            return cand
+    raise FileNotFoundError('breastmnist.npz not found (use --data-root)')
+
+
+def main(args):
+    seeds = [1967690937, 2286980494, 3620295971, 1662044193, 1825595160, 3054779705, 900327972, 1620954898,
+             3699850877, 3492574433][:args.seeds]
+    os.makedirs(args.out_dir, exist_ok=True)
+    results = []
+    for seed in seeds:
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        print("Loading data...")
+        if args.bars_and_stripes:
+            x, y = data_loader.bars_and_stripes(4)
+            train_X = test_X = x.astype(np.float32)
+            train_y = test_y = y
+            args.visible_units = 16
+        else:
+            (train_X, train_y), (val_X, val_y), (test_X, test_y) = data_loader.get_medmnist(find_breastmnist(args.data_root))
+            print("Data loaded")
+            print("Train train_x shape: ", train_X.shape)
+            train_X, val_X, test_X = data_loader.preprocess_images(train_X, val_X, test_X)
+        if args.binarise:
+            train_X = data_loader.binarise(train_X).astype(np.float32)
+            test_X = data_loader.binarise(test_X).astype(np.float32)
+
+        rbm = ClassificationRBM(args.visible_units, args.hidden_units, args.cd_k, num_classes=2, learning_rate=args.lr,
+                                sparse_constant=args.sparsity_coeffectient, use_cuda=not args.no_cuda, seed=seed,
+                                persistent=args.persistent)
+        device = rbm.get_device(False)   # host tensors; the class stages minibatches to the GPU
+        train_y_t = torch.from_numpy(np.array(train_y)).to(device).long()
+        test_y_t = torch.from_numpy(np.array(test_y)).to(device).long()
+        training_dataset = torch.utils.data.TensorDataset(torch.from_numpy(train_X).to(device), train_y_t)
+        test_dataset = torch.utils.data.TensorDataset(torch.from_numpy(test_X).to(device), test_y_t)
+        train_loader = torch.utils.data.DataLoader(training_dataset, batch_size=args.batch_size, shuffle=True)
+        test_loader = torch.utils.data.DataLoader(test_dataset, batch_size=len(training_dataset), shuffle=False)
+
+        loss_list, best_model, nll_list = rbm.train_rbm(train_loader=train_loader, test_loader=test_loader,
+                                                        epochs=args.epochs, method=args.type,
+                                                        generative_factor=args.generative_factor)
+        with open(f'{args.out_dir}/acc_per_epoch{seed}.pkl', 'wb') as f:
+            pickle.dump(rbm.acc_per_epoch_list, f)
+        with open(f'{args.out_dir}/auc_per_epoch{seed}.pkl', 'wb') as f:
+            pickle.dump(rbm.auc_per_epoch_list, f)
+        results.append((seed, rbm.acc_per_epoch_list[-1], rbm.auc_per_epoch_list[-1]))
+    print("seed, final test accuracy, final test AUC")
+    for r in results:
+        print(*r)
+    return results
+
+
+if __name__ == '__main__':
+    main(parser.parse_args())

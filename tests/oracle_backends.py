@@ -1,0 +1,113 @@
+"""Oracle-backed test doubles of the HIP backends (tests only).  They expose the same methods as
+rbm_ops.HipRbmOps / sampler.HipQuboOps but compute on the CPU with oracle/qbm_oracle.c, so that the HOST
+logic of the product (ClassificationRBM / Disc_QBM classes, data-parallel sharding, RNG offsets) can be
+exercised without a GPU.  The product never imports this module."""
+import numpy as np
+import torch
+
+from oracle import qbm_oracle as orc
+
+
+def _np(t, dtype=np.float32):
+    if t is None:
+        return None
+    if torch.is_tensor(t):
+        t = t.detach().cpu().numpy()
+    return np.ascontiguousarray(t, dtype=dtype)
+
+
+class OracleQuboOps:
+    """Stand-in for sampler.HipQuboOps.  `fixed` = {(clamped: bool): states uint8 [B,R,n]} replaces the sampler
+    (the reference's own tests would mock the annealer the same way)."""
+
+    def __init__(self, fixed=None):
+        self.device = torch.device("cpu")
+        self.fixed = fixed
+
+    def linear_fields(self, X, labels, W_vh, W_vo, b_h, b_o, beta_eff=1.0):
+        return torch.from_numpy(orc.qbm_linear_fields(_np(X, np.float64), labels, W_vh, W_vo, b_h, b_o, beta_eff))
+
+    def gibbs(self, lin, J, reads, sweeps, beta0=1.0, beta1=1.0, seed=0, offset=0, want_mean=True):
+        n = lin.shape[1]
+        if self.fixed is not None:
+            st = self.fixed[n]
+            return torch.from_numpy(st), torch.from_numpy(st.astype(np.float64).mean(axis=1))
+        st, mean = orc.qubo_gibbs(_np(lin), _np(J), reads, sweeps, beta0, beta1, seed, offset)
+        return torch.from_numpy(st), torch.from_numpy(mean)
+
+    def batch_stats(self, X, labels, mean, H):
+        return tuple(torch.from_numpy(a) for a in orc.qbm_batch_stats(_np(X, np.float64), labels, _np(mean, np.float64), H))
+
+
+class OracleRbmOps:
+    """Stand-in for rbm_ops.HipRbmOps (CPU tensors in and out)."""
+
+    name = "oracle-test-double"
+
+    def __init__(self):
+        self.device = torch.device("cpu")
+
+    @staticmethod
+    def _P(P):
+        return [_np(t) for t in (P.W, P.b, P.d, P.U, P.c)]
+
+    def sample_hidden(self, P, v, y=None, seed=0, offset=0, row0=0, want_p=True, want_s=False):
+        W, b, d, U, c = self._P(P)
+        p, s = orc.rbm_sample_hidden(_np(v), _np(y), W, d, U, seed, offset, row0, sample=want_s)
+        return torch.from_numpy(p), (torch.from_numpy(s) if want_s else None)
+
+    def sample_visible(self, P, h, seed=0, offset=0, row0=0, want_p=True, want_s=False):
+        W, b, d, U, c = self._P(P)
+        p, s = orc.rbm_sample_visible(_np(h), W, b, seed, offset, row0, sample=want_s)
+        return torch.from_numpy(p), (torch.from_numpy(s) if want_s else None)
+
+    def sample_class(self, P, h, seed=0, offset=0, row0=0, want_p=True, want_s=False):
+        W, b, d, U, c = self._P(P)
+        p, s = orc.rbm_sample_class(_np(h), U, c, seed, offset, row0, sample=want_s)
+        return torch.from_numpy(p), (torch.from_numpy(s) if want_s else None)
+
+    def free_energy(self, P, x):
+        W, b, d, U, c = self._P(P)
+        _, nf, p = orc.rbm_free_energy(_np(x), W, d, U, c)
+        return torch.from_numpy(nf), torch.from_numpy(p)
+
+    def to_u8(self, x):
+        return torch.as_tensor(x).to(torch.uint8)
+
+    def uniform(self, seed, offset, row0, rows, cols):
+        return torch.from_numpy(orc.philox_uniform(seed, offset, row0, rows, cols))
+
+    def _store(self, G, gW, gb, gd, gU, gc):
+        G.gW.copy_(torch.from_numpy(gW)); G.gd.copy_(torch.from_numpy(gd))
+        G.gU.copy_(torch.from_numpy(gU)); G.gc.copy_(torch.from_numpy(gc))
+        if gb is not None:
+            G.gb.copy_(torch.from_numpy(gb))
+
+    def update(self, P, G, lr, factor, batch_size, sparse, with_gb=True):
+        W, b, d, U, c = self._P(P)
+        orc.rbm_update(W, b, d, U, c, _np(G.gW), _np(G.gb) if with_gb else None, _np(G.gd), _np(G.gU), _np(G.gc),
+                       lr, factor, batch_size, sparse)
+        for t, a in zip((P.W, P.b, P.d, P.U, P.c), (W, b, d, U, c)):
+            t.copy_(torch.from_numpy(a))
+
+    def disc_step(self, P, G, x, labels, apply_update, fuse, lr, factor, batch_size, sparse):
+        W, b, d, U, c = self._P(P)
+        gW, gd, gU, gc, p, _ = orc.rbm_disc_grad(_np(x), _np(labels, np.int32), W, d, U, c)
+        self._store(G, gW, None, gd, gU, gc)
+        if apply_update:
+            self.update(P, G, lr, factor, batch_size, sparse, with_gb=False)
+        return torch.from_numpy(p)
+
+    def cd_step(self, P, G, v0, y0, k, seed, offset, row0, chain_v, chain_y, fuse, lr, factor, batch_size, sparse,
+                ws=None):
+        W, b, d, U, c = self._P(P)
+        cv = None if chain_v is None else _np(chain_v)
+        cy = None if chain_y is None else _np(chain_y)
+        ph0, vk, yk, phk = orc.rbm_cd_chain(_np(v0), _np(y0), W, b, d, U, c, k, seed, offset, row0, cv, cy)
+        if chain_v is not None:
+            chain_v.copy_(torch.from_numpy(cv.astype(np.uint8)))
+            chain_y.copy_(torch.from_numpy(cy))
+        self._store(G, *orc.rbm_two_phase_grad(_np(v0), _np(y0), ph0, vk, yk, phk))
+        if fuse:
+            self.update(P, G, lr, factor, batch_size, sparse)
+        return tuple(torch.from_numpy(a) for a in (ph0, vk.astype(np.uint8), vk.astype(np.uint8), yk, phk))

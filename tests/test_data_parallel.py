@@ -1,0 +1,89 @@
+"""CPU, world_size 2 over gloo: the data-parallel path of ClassificationRBM (one process per GPU in
+production, RCCL; here the same host code with an oracle-backed test double of the HIP ops).
+Each rank takes half of every minibatch; one all-reduce of the flat gradient buffer per step; the update
+divides by the GLOBAL batch size.  Checked against a single process that sees the whole minibatch:
+  * sampled Gibbs states are bit-identical (Philox rows are global row indices);
+  * parameters agree to fp32 rounding (the batch sum is associated differently: per-rank quartered chains
+    then a sum over ranks)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import synth_inputs
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _make(seed, data_parallel, persistent=False):
+    from oracle_backends import OracleRbmOps
+    from qbm_image_classification_amd.classification_rbm import ClassificationRBM
+
+    rbm = ClassificationRBM(16, 8, 2, num_classes=3, learning_rate=0.1, seed=seed, ops=OracleRbmOps(),
+                            data_parallel=data_parallel, persistent=persistent, keep_grads=True)
+    g = torch.Generator().manual_seed(5)
+    rbm.class_weights = torch.randn(3, 8, generator=g) * 0.3
+    rbm.hidden_bias = torch.randn(8, generator=g) * 0.2
+    return rbm
+
+
+def _steps(rbm, v, labels, lo, hi, method):
+    out = []
+    for s in range(3):
+        xb = torch.from_numpy(np.roll(v, s, axis=0)[lo:hi].copy())
+        yb = torch.from_numpy(np.roll(labels, s)[lo:hi].copy())
+        if method == "disc":
+            _, _, p = rbm.discriminative_training(xb, yb)
+            out.append(p.numpy().copy())
+        else:
+            rbm.contrastive_divergence_training(xb, yb)
+            out.append(rbm._chain_v.numpy().copy() if rbm.persistent else None)
+    return out
+
+
+def _worker(rank, world, port, method, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        v_bin, x_grey, _, labels, _ = synth_inputs(12, 16, 8, 3, 21)
+        rbm = _make(42, data_parallel=True, persistent=(method == "pcd"))
+        half = 12 // world
+        outs = _steps(rbm, x_grey if method == "disc" else v_bin, labels, rank * half, (rank + 1) * half, method)
+        ret[rank] = dict(W=rbm.weights.numpy().copy(), b=rbm.visible_bias.numpy().copy(), d=rbm.hidden_bias.numpy().copy(),
+                         U=rbm.class_weights.numpy().copy(), c=rbm.class_bias.numpy().copy(), outs=outs)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("method", ["disc", "cd", "pcd"])
+def test_two_ranks_match_single_process(method):
+    sys_path = os.path.dirname(os.path.abspath(__file__))
+    os.environ["PYTHONPATH"] = os.pathsep.join([sys_path, os.path.dirname(sys_path), os.environ.get("PYTHONPATH", "")])
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), method, ret), nprocs=2, join=True)
+    v_bin, x_grey, _, labels, _ = synth_inputs(12, 16, 8, 3, 21)
+    single = _make(42, data_parallel=False, persistent=(method == "pcd"))
+    outs = _steps(single, x_grey if method == "disc" else v_bin, labels, 0, 12, method)
+    for r in (0, 1):
+        for k, ref in (("W", single.weights), ("b", single.visible_bias), ("d", single.hidden_bias),
+                       ("U", single.class_weights), ("c", single.class_bias)):
+            assert np.allclose(ret[r][k], ref.numpy(), rtol=0, atol=2e-6), (method, r, k)
+    assert np.array_equal(ret[0]["W"], ret[1]["W"])                      # replicas stay bit-identical
+    if method == "disc":
+        for s in range(3):
+            both = np.concatenate([ret[0]["outs"][s], ret[1]["outs"][s]])
+            assert np.allclose(both, outs[s], rtol=0, atol=2e-6)
+    if method == "pcd":
+        # first step: same parameters on both sides, so the persistent chains must be the same BITS
+        both = np.concatenate([ret[0]["outs"][0], ret[1]["outs"][0]])
+        assert np.array_equal(both, outs[0])

@@ -12,7 +12,7 @@ What is pinned:
   rbm_prims_*.npz     sample_hidden/visible/class (:43-60), sample_class_given_x (:62-86) + the
                       intermediate -F rebuilt exactly as :65-74 (fp32, sequential) and an fp64 companion
   rbm_disc_*.npz      three consecutive discriminative_training steps (:101-146, :88-99)
-  rbm_train_breast.npz train_rbm for 2 epochs on a 64-image BreastMNIST subset (:159-205, :251-294)
+  rbm_train_breast.npz train_rbm for 2 epochs on a 63-image BreastMNIST subset (:159-205, :251-294)
   qbm_*.npz           Disc_QBM numpy methods (src/model/faster_dqbm.py) run from the real source with
                       stub modules for the absent D-Wave packages: ctor params (:58-223), QUBO matrices
                       (:225-284), batch statistics (:754-848), one train_for_one_iteration update
@@ -190,7 +190,11 @@ def gen_rbm():
     finally:
         os.chdir(cwd)
 
-    n_tr, n_te = 64, 32
+    # 63 = 9 x 7: no trailing minibatch of ONE sample.  With a single row the reference's in-place
+    # squeeze_() (src/ClassificationRBM.py:134) drops the batch axis too and the hidden-bias gradient becomes the
+    # scalar sum over hidden units, broadcast to every bias -- a quirk its own runs never hit (546 % 7 == 0) and
+    # that the build does not mirror ('Reference quirks').
+    n_tr, n_te = 63, 32
     X = trXf[:n_tr].astype(np.float32)
     Y = np.array(trY[:n_tr]).astype(np.int64)
     Xt = teXf[:n_te].astype(np.float32)
