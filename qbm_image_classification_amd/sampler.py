@@ -109,6 +109,13 @@ class HipGibbsSampler:
         n = Q.shape[0]
         lin = np.diag(Q).astype(np.float32)[None, :]
         off = Q - np.diag(np.diag(Q))
+        if not off.any():
+            # the reference short-circuits a QUBO without quadratic terms (src/qubo/sampler.py:13-17, 28-29):
+            # s_i = 1 if h_i < 0, 0 if h_i > 0, a coin (one draw per variable, shared by all reads) if h_i == 0
+            h = np.diag(Q)
+            coin = np.random.default_rng(self.seed).integers(0, 2, size=n)
+            sol = np.where(h < 0, 1, np.where(h > 0, 0, coin)).astype(np.float32)
+            return np.tile(sol, (int(num_reads), 1))
         J = (off + off.T).astype(np.float32)
         b0, b1 = self.beta_range if self.beta_range is not None else auto_beta_range(lin, J)
         states, _ = self.ops.gibbs(torch.from_numpy(lin), torch.from_numpy(J), int(num_reads), self.num_sweeps,
