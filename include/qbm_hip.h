@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define QBM_ABI_VERSION 2
-#define QBM_MAX_CLASSES 31 /* class rows + the bias row share one 32-row gradient strip */
+#define QBM_MAX_CLASSES 15 /* class rows + the bias row share one 16-row gradient tile */
 #define QBM_MAX_QUBO_VARS 1024
 
 /* element type of a Gibbs-state tensor: fp32 (what the reference holds) or uint8 {0,1} (exact for

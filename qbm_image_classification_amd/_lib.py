@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libqbm_hip.so")
 
 QBM_ABI_VERSION = 2
-QBM_MAX_CLASSES = 31
+QBM_MAX_CLASSES = 15
 QBM_F32, QBM_U8 = 0, 1
 
 

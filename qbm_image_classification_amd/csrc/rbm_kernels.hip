@@ -24,7 +24,15 @@ int hip_fail(hipError_t e, const char* where)
 
 namespace {
 
-constexpr int MT = 2, NT = 1;  // every strip is 32 rows x 16 columns: two row tiles share each staged B fragment
+// Strip shapes (rows = 16*MT, columns = 16*NT), chosen so that one launch of the benchmark shape fills the
+// 256 CUs in a single round with one workgroup per CU (two workgroups on a CU share its MFMA pipes and its
+// L2 -> LDS path, which costs more than the larger strip):
+//   hidden  : [256 x 512], K = 784 -> 32 x 16 strips: 8 x 32 = 256 workgroups
+//   visible : [256 x 784], K = 512 -> 64 x 16 strips: 4 x 49 = 196 workgroups (+ 32 class workgroups)
+//   gradient: [784 x 512], K = 256 x 2 phases -> 64 x 32 strips: 13 x 16 = 208 workgroups (+ 30 for gU/gd/gb/gc)
+constexpr int H_MT = 2, H_NT = 1;
+constexpr int V_MT = 4, V_NT = 1;
+constexpr int G_MT = 4, G_NT = 2;
 
 // class-count buckets for the kernels that keep one register (or one float4) per class
 #define QBM_DISPATCH_CM(C, MACRO)                   \
@@ -72,6 +80,7 @@ struct HiddenArgs {
 template <class TA, bool FAST, int MODE, int CM>
 __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
 {
+    constexpr int MT = H_MT, NT = H_NT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int nM = (a.B + 16 * MT - 1) / (16 * MT), nN = (a.H + 16 * NT - 1) / (16 * NT);
     int ms, ns;
@@ -79,73 +88,76 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
     const int m0 = ms * 16 * MT, n0 = ns * 16 * NT;
     const typename KView<TA>::type A{reinterpret_cast<const TA*>(a.v), a.V, a.B};
     const ViewCContig Bv{a.W, a.H, a.H, a.V};
-    const StripOut o = strip_mma<MT, NT, FAST>(A, Bv, m0, n0, a.V, lds, a.KP);
-    if (!o.valid) return;
-    const int i = m0 + o.row, j0 = n0 + 4 * o.cg;
-    if (i >= a.B || j0 >= a.H) return;
-    const bool vec = a.vecO && j0 + 3 < a.H;
-    const float sv[4] = {o.sum.x, o.sum.y, o.sum.z, o.sum.w};
-    // every load below is unconditional (indices clamped into range) so that they are all in flight
-    // together; classes c >= C enter the chain as fmaf(0, u, cls), which is exact
-    float dv[4], cls[4] = {0.f, 0.f, 0.f, 0.f};
-    if (vec) {
-        const float4 t = *reinterpret_cast<const float4*>(a.d + j0);
-        dv[0] = t.x; dv[1] = t.y; dv[2] = t.z; dv[3] = t.w;
-    } else {
+    const auto o = strip_mma<MT, NT, FAST, FAST>(A, Bv, m0, n0, a.V, lds, a.KP);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dv[e] = a.d[min(j0 + e, a.H - 1)];
-    }
-    if (MODE == 0 && a.y) {
-        float yv[CM];
-#pragma unroll
-        for (int c = 0; c < CM; ++c) {
-            const float t = a.y[(long)i * a.C + min(c, a.C - 1)];
-            yv[c] = (c < a.C) ? t : 0.f;
-        }
+    for (int op = 0; op < o.NP; ++op) {
+        if (!o.valid(op)) continue;
+        const int i = m0 + o.row(op), j0 = n0 + 4 * o.cg(op);
+        if (i >= a.B || j0 >= a.H) continue;
+        const bool vec = a.vecO && j0 + 3 < a.H;
+        const float sv[4] = {o.sum[op].x, o.sum[op].y, o.sum[op].z, o.sum[op].w};
+        // every load below is unconditional (indices clamped into range) so that they are all in flight
+        // together; classes c >= C enter the chain as fmaf(0, u, cls), which is exact
+        float dv[4], cls[4] = {0.f, 0.f, 0.f, 0.f};
         if (vec) {
-            float4 uv[CM];
+            const float4 t = *reinterpret_cast<const float4*>(a.d + j0);
+            dv[0] = t.x; dv[1] = t.y; dv[2] = t.z; dv[3] = t.w;
+        } else {
 #pragma unroll
-            for (int c = 0; c < CM; ++c) uv[c] = *reinterpret_cast<const float4*>(a.U + (long)min(c, a.C - 1) * a.H + j0);
+            for (int e = 0; e < 4; ++e) dv[e] = a.d[min(j0 + e, a.H - 1)];
+        }
+        if (MODE == 0 && a.y) {
+            float yv[CM];
 #pragma unroll
             for (int c = 0; c < CM; ++c) {
-                cls[0] = __builtin_fmaf(yv[c], uv[c].x, cls[0]);
-                cls[1] = __builtin_fmaf(yv[c], uv[c].y, cls[1]);
-                cls[2] = __builtin_fmaf(yv[c], uv[c].z, cls[2]);
-                cls[3] = __builtin_fmaf(yv[c], uv[c].w, cls[3]);
+                const float t = a.y[(long)i * a.C + min(c, a.C - 1)];
+                yv[c] = (c < a.C) ? t : 0.f;
             }
-        } else {
+            if (vec) {
+                float4 uv[CM];
 #pragma unroll
-            for (int c = 0; c < CM; ++c)
+                for (int c = 0; c < CM; ++c) uv[c] = *reinterpret_cast<const float4*>(a.U + (long)min(c, a.C - 1) * a.H + j0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    cls[e] = __builtin_fmaf(yv[c], a.U[(long)min(c, a.C - 1) * a.H + min(j0 + e, a.H - 1)], cls[e]);
+                for (int c = 0; c < CM; ++c) {
+                    cls[0] = __builtin_fmaf(yv[c], uv[c].x, cls[0]);
+                    cls[1] = __builtin_fmaf(yv[c], uv[c].y, cls[1]);
+                    cls[2] = __builtin_fmaf(yv[c], uv[c].z, cls[2]);
+                    cls[3] = __builtin_fmaf(yv[c], uv[c].w, cls[3]);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CM; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        cls[e] = __builtin_fmaf(yv[c], a.U[(long)min(c, a.C - 1) * a.H + min(j0 + e, a.H - 1)], cls[e]);
+            }
         }
-    }
-    float pv[4], hv[4];
-    f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (MODE == 0 && (a.s || a.s8)) u = uniform4(a.seed, a.offset, a.row0 + (uint32_t)i, (uint32_t)(j0 >> 2));
+        float pv[4], hv[4];
+        f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (MODE == 0 && (a.s || a.s8)) u = uniform4(a.seed, a.offset, a.row0 + (uint32_t)i, (uint32_t)(j0 >> 2));
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        float x = sv[e] + dv[e];
-        if (MODE == 0) {
-            if (a.y) x = x + cls[e];
-            pv[e] = det_sigmoid(x);
-            hv[e] = (pv[e] > u[e]) ? 1.f : 0.f;
-        } else {
-            pv[e] = x; hv[e] = 0.f;
+        for (int e = 0; e < 4; ++e) {
+            float x = sv[e] + dv[e];
+            if (MODE == 0) {
+                if (a.y) x = x + cls[e];
+                pv[e] = det_sigmoid(x);
+                hv[e] = (pv[e] > u[e]) ? 1.f : 0.f;
+            } else {
+                pv[e] = x; hv[e] = 0.f;
+            }
         }
-    }
-    const long off = (long)i * a.H + j0;
-    if (vec) {
-        if (a.p) *reinterpret_cast<float4*>(a.p + off) = make_float4(pv[0], pv[1], pv[2], pv[3]);
-        if (MODE == 0 && a.s) *reinterpret_cast<float4*>(a.s + off) = make_float4(hv[0], hv[1], hv[2], hv[3]);
-        if (MODE == 0 && a.s8)
-            *reinterpret_cast<uint32_t*>(a.s8 + off) = (uint32_t)hv[0] | ((uint32_t)hv[1] << 8) | ((uint32_t)hv[2] << 16) | ((uint32_t)hv[3] << 24);
-    } else {
-        for (int e = 0; e < 4 && j0 + e < a.H; ++e) {
-            if (a.p) a.p[off + e] = pv[e];
-            if (MODE == 0 && a.s) a.s[off + e] = hv[e];
-            if (MODE == 0 && a.s8) a.s8[off + e] = (uint8_t)hv[e];
+        const long off = (long)i * a.H + j0;
+        if (vec) {
+            if (a.p) *reinterpret_cast<float4*>(a.p + off) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+            if (MODE == 0 && a.s) *reinterpret_cast<float4*>(a.s + off) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+            if (MODE == 0 && a.s8)
+                *reinterpret_cast<uint32_t*>(a.s8 + off) = (uint32_t)hv[0] | ((uint32_t)hv[1] << 8) | ((uint32_t)hv[2] << 16) | ((uint32_t)hv[3] << 24);
+        } else {
+            for (int e = 0; e < 4 && j0 + e < a.H; ++e) {
+                if (a.p) a.p[off + e] = pv[e];
+                if (MODE == 0 && a.s) a.s[off + e] = hv[e];
+                if (MODE == 0 && a.s8) a.s8[off + e] = (uint8_t)hv[e];
+            }
         }
     }
 }
@@ -253,45 +265,49 @@ __global__ __launch_bounds__(256) void k_visible(VisibleArgs a)
                 class_row<TA, CM>(a.h, a.U, a.cb, a.py, a.ys, base + r, a.H, a.C, a.seed, a.offset_y, a.row0, threadIdx.x & 63);
         return;
     }
+    constexpr int MT = V_MT, NT = V_NT;
     const int nM = (a.B + 16 * MT - 1) / (16 * MT), nN = (a.V + 16 * NT - 1) / (16 * NT);
     int ms, ns;
     strip_coords(nM, nN, ms, ns, a.n_aux);
     const int m0 = ms * 16 * MT, n0 = ns * 16 * NT;
     const typename KView<TA>::type A{reinterpret_cast<const TA*>(a.h), a.H, a.B};
     const ViewKContig Bv{a.W, a.H, a.V};
-    const StripOut o = strip_mma<MT, NT, FAST>(A, Bv, m0, n0, a.H, lds, a.KP);
-    if (!o.valid) return;
-    const int i = m0 + o.row, k0 = n0 + 4 * o.cg;
-    if (i >= a.B || k0 >= a.V) return;
-    const bool vec = a.vecO && k0 + 3 < a.V;
-    const float sv[4] = {o.sum.x, o.sum.y, o.sum.z, o.sum.w};
-    float bv[4];
-    if (vec) {
-        const float4 t = *reinterpret_cast<const float4*>(a.b + k0);
-        bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
-    } else {
+    const auto o = strip_mma<MT, NT, FAST, FAST>(A, Bv, m0, n0, a.H, lds, a.KP);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bv[e] = a.b[min(k0 + e, a.V - 1)];
-    }
-    float pv[4], vv[4];
-    f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (a.s || a.s8) u = uniform4(a.seed, a.offset, a.row0 + (uint32_t)i, (uint32_t)(k0 >> 2));
+    for (int op = 0; op < o.NP; ++op) {
+        if (!o.valid(op)) continue;
+        const int i = m0 + o.row(op), k0 = n0 + 4 * o.cg(op);
+        if (i >= a.B || k0 >= a.V) continue;
+        const bool vec = a.vecO && k0 + 3 < a.V;
+        const float sv[4] = {o.sum[op].x, o.sum[op].y, o.sum[op].z, o.sum[op].w};
+        float bv[4];
+        if (vec) {
+            const float4 t = *reinterpret_cast<const float4*>(a.b + k0);
+            bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
+        } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        pv[e] = det_sigmoid(sv[e] + bv[e]);
-        vv[e] = (pv[e] > u[e]) ? 1.f : 0.f;
-    }
-    const long off = (long)i * a.V + k0;
-    if (vec) {
-        if (a.p) *reinterpret_cast<float4*>(a.p + off) = make_float4(pv[0], pv[1], pv[2], pv[3]);
-        if (a.s) *reinterpret_cast<float4*>(a.s + off) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-        if (a.s8)
-            *reinterpret_cast<uint32_t*>(a.s8 + off) = (uint32_t)vv[0] | ((uint32_t)vv[1] << 8) | ((uint32_t)vv[2] << 16) | ((uint32_t)vv[3] << 24);
-    } else {
-        for (int e = 0; e < 4 && k0 + e < a.V; ++e) {
-            if (a.p) a.p[off + e] = pv[e];
-            if (a.s) a.s[off + e] = vv[e];
-            if (a.s8) a.s8[off + e] = (uint8_t)vv[e];
+            for (int e = 0; e < 4; ++e) bv[e] = a.b[min(k0 + e, a.V - 1)];
+        }
+        float pv[4], vv[4];
+        f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.s || a.s8) u = uniform4(a.seed, a.offset, a.row0 + (uint32_t)i, (uint32_t)(k0 >> 2));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            pv[e] = det_sigmoid(sv[e] + bv[e]);
+            vv[e] = (pv[e] > u[e]) ? 1.f : 0.f;
+        }
+        const long off = (long)i * a.V + k0;
+        if (vec) {
+            if (a.p) *reinterpret_cast<float4*>(a.p + off) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+            if (a.s) *reinterpret_cast<float4*>(a.s + off) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            if (a.s8)
+                *reinterpret_cast<uint32_t*>(a.s8 + off) = (uint32_t)vv[0] | ((uint32_t)vv[1] << 8) | ((uint32_t)vv[2] << 16) | ((uint32_t)vv[3] << 24);
+        } else {
+            for (int e = 0; e < 4 && k0 + e < a.V; ++e) {
+                if (a.p) a.p[off + e] = pv[e];
+                if (a.s) a.s[off + e] = vv[e];
+                if (a.s8) a.s8[off + e] = (uint8_t)vv[e];
+            }
         }
     }
 }
@@ -447,60 +463,73 @@ __device__ __forceinline__ float upd(float th, float g, const GradArgs& a, bool 
 template <class T0, class T1, bool FAST>
 __global__ __launch_bounds__(256) void k_grad(GradArgs a)
 {
+    constexpr int MT = G_MT, NT = G_NT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     int blk = blockIdx.x;
     const ViewCContig P0{a.P0, a.H, a.H, a.B}, P1{a.P1, a.H, a.H, a.B};
     const typename CView<T0>::type D0{reinterpret_cast<const T0*>(a.A0), a.V, a.V, a.B};
     const typename CView<T1>::type D1{reinterpret_cast<const T1*>(a.A1), a.V, a.V, a.B};
-    if (blk < a.nU) {  // class-weight rows and the hidden-bias row (C + 1 <= 32 rows) x 16 hidden columns
+    if (blk < a.nU) {  // class-weight rows and the hidden-bias row (C + 1 <= 16 rows: one row tile) x 16*NT hidden columns
         const int n0 = blk * 16 * NT;
         const ViewAugY Y0{a.Y0, a.C}, Y1{a.Y1, a.C};
-        const StripOut o0 = strip_mma<MT, NT, false>(Y0, P0, 0, n0, a.B, lds, a.KP);
-        const StripOut o1 = strip_mma<MT, NT, false>(Y1, P1, 0, n0, a.B, lds, a.KP);
-        if (!o0.valid || o0.row > a.C) return;
-        const float g[4] = {o0.sum.x - o1.sum.x, o0.sum.y - o1.sum.y, o0.sum.z - o1.sum.z, o0.sum.w - o1.sum.w};
-        for (int e = 0; e < 4; ++e) {
-            const int n = n0 + 4 * o0.cg + e;
-            if (n >= a.H) break;
-            if (o0.row < a.C) {
-                const long off = (long)o0.row * a.H + n;
-                if (a.gU) a.gU[off] = g[e];
-                if (a.uU) a.uU[off] = upd(a.uU[off], g[e], a, false);
-            } else {
-                if (a.gd) a.gd[n] = g[e];
-                if (a.ud) a.ud[n] = upd(a.ud[n], g[e], a, true);
+        const auto o0 = strip_mma<1, NT, false, FAST>(Y0, P0, 0, n0, a.B, lds, a.KP);
+        const auto o1 = strip_mma<1, NT, false, FAST>(Y1, P1, 0, n0, a.B, lds, a.KP);
+#pragma unroll
+        for (int op = 0; op < o0.NP; ++op) {
+            if (!o0.valid(op) || o0.row(op) > a.C) continue;
+            const int row = o0.row(op);
+            const float g[4] = {o0.sum[op].x - o1.sum[op].x, o0.sum[op].y - o1.sum[op].y, o0.sum[op].z - o1.sum[op].z,
+                                o0.sum[op].w - o1.sum[op].w};
+            for (int e = 0; e < 4; ++e) {
+                const int n = n0 + 4 * o0.cg(op) + e;
+                if (n >= a.H) break;
+                if (row < a.C) {
+                    const long off = (long)row * a.H + n;
+                    if (a.gU) a.gU[off] = g[e];
+                    if (a.uU) a.uU[off] = upd(a.uU[off], g[e], a, false);
+                } else {
+                    if (a.gd) a.gd[n] = g[e];
+                    if (a.ud) a.ud[n] = upd(a.ud[n], g[e], a, true);
+                }
             }
         }
         return;
     }
     blk -= a.nU;
-    if (blk < a.nB) {  // visible bias: column sums of the data = data^T . ones, 32 visible units per workgroup
+    if (blk < a.nB) {  // visible bias: column sums of the data = data^T . ones, 16*MT visible units per workgroup
         const int m0 = blk * 16 * MT;
         const ViewOnesCol ones;
-        const StripOut o0 = strip_mma<MT, NT, false>(D0, ones, m0, 0, a.B, lds, a.KP);
-        const StripOut o1 = strip_mma<MT, NT, false>(D1, ones, m0, 0, a.B, lds, a.KP);
-        if (!o0.valid || o0.cg != 0) return;
-        const int m = m0 + o0.row;
-        if (m >= a.V) return;
-        const float g = o0.sum.x - o1.sum.x;
-        if (a.gb) a.gb[m] = g;
-        if (a.ub) a.ub[m] = upd(a.ub[m], g, a, true);
+        const auto o0 = strip_mma<MT, 1, FAST, false>(D0, ones, m0, 0, a.B, lds, a.KP);
+        const auto o1 = strip_mma<MT, 1, FAST, false>(D1, ones, m0, 0, a.B, lds, a.KP);
+#pragma unroll
+        for (int op = 0; op < o0.NP; ++op) {
+            if (!o0.valid(op) || o0.cg(op) != 0) continue;
+            const int m = m0 + o0.row(op);
+            if (m >= a.V) continue;
+            const float g = o0.sum[op].x - o1.sum[op].x;
+            if (a.gb) a.gb[m] = g;
+            if (a.ub) a.ub[m] = upd(a.ub[m], g, a, true);
+        }
         return;
     }
     blk -= a.nB;
-    if (blk < a.nC) {  // class bias: column sums of the labels = ones^T . Y, 16 classes per workgroup
+    if (blk < a.nC) {  // class bias: column sums of the labels = ones^T . Y, 16*NT classes per workgroup
         const int n0 = blk * 16 * NT;
         const ViewOnesRow ones;
         const ViewCContig Y0{a.Y0, a.C, a.C, a.B}, Y1{a.Y1, a.C, a.C, a.B};
-        const StripOut o0 = strip_mma<MT, NT, false>(ones, Y0, 0, n0, a.B, lds, a.KP);
-        const StripOut o1 = strip_mma<MT, NT, false>(ones, Y1, 0, n0, a.B, lds, a.KP);
-        if (!o0.valid || o0.row != 0) return;
-        const float g[4] = {o0.sum.x - o1.sum.x, o0.sum.y - o1.sum.y, o0.sum.z - o1.sum.z, o0.sum.w - o1.sum.w};
-        for (int e = 0; e < 4; ++e) {
-            const int n = n0 + 4 * o0.cg + e;
-            if (n >= a.C) break;
-            if (a.gc) a.gc[n] = g[e];
-            if (a.uc) a.uc[n] = upd(a.uc[n], g[e], a, true);
+        const auto o0 = strip_mma<1, NT, false, false>(ones, Y0, 0, n0, a.B, lds, a.KP);
+        const auto o1 = strip_mma<1, NT, false, false>(ones, Y1, 0, n0, a.B, lds, a.KP);
+#pragma unroll
+        for (int op = 0; op < o0.NP; ++op) {
+            if (!o0.valid(op) || o0.row(op) != 0) continue;
+            const float g[4] = {o0.sum[op].x - o1.sum[op].x, o0.sum[op].y - o1.sum[op].y, o0.sum[op].z - o1.sum[op].z,
+                                o0.sum[op].w - o1.sum[op].w};
+            for (int e = 0; e < 4; ++e) {
+                const int n = n0 + 4 * o0.cg(op) + e;
+                if (n >= a.C) break;
+                if (a.gc) a.gc[n] = g[e];
+                if (a.uc) a.uc[n] = upd(a.uc[n], g[e], a, true);
+            }
         }
         return;
     }
@@ -508,26 +537,30 @@ __global__ __launch_bounds__(256) void k_grad(GradArgs a)
     int ms, ns;
     strip_coords(nM, nN, ms, ns, a.nU + a.nB + a.nC);
     const int m0 = ms * 16 * MT, n0 = ns * 16 * NT;
-    const StripOut o0 = strip_mma<MT, NT, FAST>(D0, P0, m0, n0, a.B, lds, a.KP);
-    const StripOut o1 = strip_mma<MT, NT, FAST>(D1, P1, m0, n0, a.B, lds, a.KP);
-    if (!o0.valid) return;
-    const int m = m0 + o0.row, nb = n0 + 4 * o0.cg;
-    if (m >= a.V || nb >= a.H) return;
-    const float g[4] = {o0.sum.x - o1.sum.x, o0.sum.y - o1.sum.y, o0.sum.z - o1.sum.z, o0.sum.w - o1.sum.w};
-    const long off = (long)m * a.H + nb;
-    if (nb + 3 < a.H && a.vecO) {
-        if (a.gW) *reinterpret_cast<float4*>(a.gW + off) = make_float4(g[0], g[1], g[2], g[3]);
-        if (a.W) {
-            float4 w = *reinterpret_cast<const float4*>(a.W + off);
-            w.x = upd(w.x, g[0], a, false); w.y = upd(w.y, g[1], a, false);
-            w.z = upd(w.z, g[2], a, false); w.w = upd(w.w, g[3], a, false);
-            *reinterpret_cast<float4*>(a.W + off) = w;
+    const auto o0 = strip_mma<MT, NT, FAST, FAST>(D0, P0, m0, n0, a.B, lds, a.KP);
+    const auto o1 = strip_mma<MT, NT, FAST, FAST>(D1, P1, m0, n0, a.B, lds, a.KP);
+#pragma unroll
+    for (int op = 0; op < o0.NP; ++op) {
+        if (!o0.valid(op)) continue;
+        const int m = m0 + o0.row(op), nb = n0 + 4 * o0.cg(op);
+        if (m >= a.V || nb >= a.H) continue;
+        const float g[4] = {o0.sum[op].x - o1.sum[op].x, o0.sum[op].y - o1.sum[op].y, o0.sum[op].z - o1.sum[op].z,
+                            o0.sum[op].w - o1.sum[op].w};
+        const long off = (long)m * a.H + nb;
+        if (nb + 3 < a.H && a.vecO) {
+            if (a.gW) *reinterpret_cast<float4*>(a.gW + off) = make_float4(g[0], g[1], g[2], g[3]);
+            if (a.W) {
+                float4 w = *reinterpret_cast<const float4*>(a.W + off);
+                w.x = upd(w.x, g[0], a, false); w.y = upd(w.y, g[1], a, false);
+                w.z = upd(w.z, g[2], a, false); w.w = upd(w.w, g[3], a, false);
+                *reinterpret_cast<float4*>(a.W + off) = w;
+            }
+            continue;
         }
-        return;
-    }
-    for (int e = 0; e < 4 && nb + e < a.H; ++e) {
-        if (a.gW) a.gW[off + e] = g[e];
-        if (a.W) a.W[off + e] = upd(a.W[off + e], g[e], a, false);
+        for (int e = 0; e < 4 && nb + e < a.H; ++e) {
+            if (a.gW) a.gW[off + e] = g[e];
+            if (a.W) a.W[off + e] = upd(a.W[off + e], g[e], a, false);
+        }
     }
 }
 
@@ -591,7 +624,7 @@ __global__ void k_f32_to_u8(const float* __restrict__ x, uint8_t* __restrict__ y
 }
 
 // ---- launch helpers ---------------------------------------------------------------------------
-template <int ASZ>
+template <int MT, int NT, int ASZ>
 int panel_for(int K)
 {
     const int Kq = quarter_len(K);
@@ -628,8 +661,8 @@ template <class TA>
 int launch_hidden_t(const qbm_rbm_params* P, const void* v, const float* y, int B, float* p, float* s, uint8_t* s8,
                     int mode, uint64_t seed, uint64_t offset, uint32_t row0, hipStream_t st)
 {
-    constexpr int ASZ = (int)sizeof(TA);
-    HiddenArgs a{v, y, P->W, P->d, P->U, p, s, s8, B, P->V, P->H, P->C, panel_for<ASZ>(P->V), seed, offset, row0,
+    constexpr int ASZ = (int)sizeof(TA), MT = H_MT, NT = H_NT;
+    HiddenArgs a{v, y, P->W, P->d, P->U, p, s, s8, B, P->V, P->H, P->C, panel_for<MT, NT, ASZ>(P->V), seed, offset, row0,
                  (P->H % 4 == 0) && (!p || aligned16(p)) && (!s || aligned16(s)) && (!s8 || aligned16(s8)) &&
                      aligned16(P->d) && aligned16(P->U)};
     // LDS-DMA path: whole 16-k pieces, 16-byte aligned units, descriptors below 2 GiB
@@ -667,10 +700,10 @@ template <class TA>
 int launch_visible_t(const qbm_rbm_params* P, const void* h, int B, float* p_v, float* v_s, uint8_t* v_s8, float* p_y,
                      float* y1hot, uint64_t seed, uint64_t offset_v, uint64_t offset_y, uint32_t row0, hipStream_t st)
 {
-    constexpr int ASZ = (int)sizeof(TA);
+    constexpr int ASZ = (int)sizeof(TA), MT = V_MT, NT = V_NT;
     const bool with_class = p_y || y1hot;
     const int nM = (B + 16 * MT - 1) / (16 * MT), nN = (P->V + 16 * NT - 1) / (16 * NT);
-    VisibleArgs a{h, P->W, P->b, p_v, v_s, v_s8, B, P->V, P->H, panel_for<ASZ>(P->H), seed, offset_v, row0,
+    VisibleArgs a{h, P->W, P->b, p_v, v_s, v_s8, B, P->V, P->H, panel_for<MT, NT, ASZ>(P->H), seed, offset_v, row0,
                   (P->V % 4 == 0) && (!p_v || aligned16(p_v)) && (!v_s || aligned16(v_s)) && (!v_s8 || aligned16(v_s8)) &&
                       aligned16(P->b),
                   P->U, P->c, p_y, y1hot, P->C, offset_y, with_class ? (B + 7) / 8 : 0};
@@ -706,13 +739,14 @@ int launch_grad_t(int V, int H, int C, int B, const void* A0, const float* Y0, c
                   const float* Y1, const float* P1, const qbm_rbm_grads* G, float* W_fused, const qbm_rbm_params* aux_fused,
                   float lr, float factor, float bs, float sparse, hipStream_t st)
 {
+    constexpr int MT = G_MT, NT = G_NT;
     const int nM = (V + 16 * MT - 1) / (16 * MT), nN = (H + 16 * NT - 1) / (16 * NT);
     const bool want_b = G->gb || (aux_fused && aux_fused->b);
     const bool want_c = G->gc || (aux_fused && aux_fused->c);
     GradArgs a{A0, Y0, P0, A1, Y1, P1, G->gW, G->gb, G->gd, G->gU, G->gc, W_fused,
                aux_fused ? aux_fused->b : nullptr, aux_fused ? aux_fused->d : nullptr,
                aux_fused ? aux_fused->U : nullptr, aux_fused ? aux_fused->c : nullptr,
-               lr, factor, bs, sparse, B, V, H, C, panel_for<4>(B),
+               lr, factor, bs, sparse, B, V, H, C, panel_for<MT, NT, 4>(B),
                nN, want_b ? nM : 0, want_c ? (C + 16 * NT - 1) / (16 * NT) : 0,
                (H % 4 == 0) && (!G->gW || aligned16(G->gW)) && (!W_fused || aligned16(W_fused))};
     const bool fast = (B % 16 == 0) && (V % 16 == 0) && (H % 4 == 0) && aligned16(A0) && aligned16(A1) && aligned16(P0) &&
@@ -734,7 +768,7 @@ int launch_grad(int V, int H, int C, int B, const void* A0, int d0, const float*
                 const float* Y1, const float* P1, const qbm_rbm_grads* G, float* W_fused, const qbm_rbm_params* aux_fused,
                 float lr, float factor, float bs, float sparse, hipStream_t st)
 {
-    if (C + 1 > 16 * MT) return fail(QBM_ERR_ARG, "two_phase_grad: C + 1 must fit one 32-row strip");
+    if (C + 1 > 16) return fail(QBM_ERR_ARG, "two_phase_grad: at most 15 classes (class rows + the bias row share one 16-row tile)");
 #define QBM_G(T0, T1) launch_grad_t<T0, T1>(V, H, C, B, A0, Y0, P0, A1, Y1, P1, G, W_fused, aux_fused, lr, factor, bs, sparse, st)
     if (d0 == QBM_U8) return d1 == QBM_U8 ? QBM_G(uint8_t, uint8_t) : QBM_G(uint8_t, float);
     return d1 == QBM_U8 ? QBM_G(float, uint8_t) : QBM_G(float, float);

@@ -261,11 +261,16 @@ __host__ __device__ constexpr int strip_max_panel()
     return kp;
 }
 
+// What one thread holds after the four partial strips are combined: NP = ceil(MT*NT/4) outputs; output p of
+// thread t is row (t + 256p) / (4*NT), column group (t + 256p) % (4*NT) of the strip (4 consecutive columns),
+// sum[p] = ((q0+q1)+q2)+q3.
+template <int MT, int NT>
 struct StripOut {
-    float4 sum;  // ((q0+q1)+q2)+q3 for columns n0+4*cg .. +3 of row m0+row
-    int row;     // 0..16*MT-1
-    int cg;      // 0..4*NT-1
-    bool valid;  // this thread holds an output
+    static constexpr int NP = (MT * NT + 3) / 4;
+    float4 sum[NP];
+    __device__ __forceinline__ static bool valid(int p) { return (int)threadIdx.x + 256 * p < 64 * MT * NT; }
+    __device__ __forceinline__ static int row(int p) { return ((int)threadIdx.x + 256 * p) / (4 * NT); }
+    __device__ __forceinline__ static int cg(int p) { return ((int)threadIdx.x + 256 * p) % (4 * NT); }
 };
 
 // wait until at most n of this wave's vector-memory operations (LDS-DMA pieces included) are outstanding.
@@ -288,10 +293,10 @@ __device__ __forceinline__ void vm_wait(int n)
 }
 
 // KP: panel length, multiple of 64.  lds: the workgroup's dynamic LDS (strip_lds_bytes<MT,NT,sizeof(elem)>(KP)).
-// FAST: both operands are staged by LDS-DMA (the host guarantees alignment and whole 16-byte units);
-// otherwise values go through registers (any shape, any alignment).
-template <int MT, int NT, bool FAST, class AView, class BView>
-__device__ __forceinline__ StripOut strip_mma(const AView& A, const BView& Bv, int m0, int n0, int K,
+// FAST_A / FAST_B: the operand is staged by LDS-DMA (the host guarantees alignment and whole 16-byte units);
+// otherwise its values go through registers (any shape, any alignment, synthesised operands).
+template <int MT, int NT, bool FAST_A, bool FAST_B, class AView, class BView>
+__device__ __forceinline__ StripOut<MT, NT> strip_mma(const AView& A, const BView& Bv, int m0, int n0, int K,
                                               char* __restrict__ lds, int KP)
 {
     using TA = typename AView::elem;
@@ -374,7 +379,7 @@ __device__ __forceinline__ StripOut strip_mma(const AView& A, const BView& Bv, i
     for (int kb = kq0; kb < kq0 + Kq; kb += KP) {
         const int klen = max(0, min(kend - kb, KP));
         const int pieces = (klen + 15) >> 4;   // 16 k per piece (klen is a multiple of 16 on the FAST path)
-        if constexpr (FAST) {
+        if constexpr (FAST_A && FAST_B) {
             // ---- LDS-DMA: every instruction of this wave's K range is issued before anything is waited for.
             // Issue order: per piece [A tiles (u8: once per 4 pieces), B tiles].
             const rsrc_t ra = A.rsrc(), rb = Bv.rsrc();
@@ -415,9 +420,20 @@ __device__ __forceinline__ StripOut strip_mma(const AView& A, const BView& Bv, i
             vm_wait(0);
             if (QBM_DIAG_MODE != 3) run(half, pieces);
         } else {
-            // ---- generic path (unaligned / ragged / synthesised operands): values through registers
+            // ---- at least one operand goes through registers (unaligned / ragged / synthesised)
             const int quads = (pieces + 3) >> 2;
-            if constexpr (A8) {
+            if constexpr (FAST_A) {
+                const rsrc_t ra = A.rsrc();
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    DmaLane la = A.lane0(m0 + 16 * i, kb, lane);
+                    for (int g = 0; g < (A8 ? quads : pieces); ++g) {
+                        blds16(ra, (!A8 || la.k < kend) ? la.voff : kOOB, imgA + i * a_tile + g * 1024);
+                        la.voff += la.step;
+                        la.k += la.kstep;
+                    }
+                }
+            } else if constexpr (A8) {
                 for (int g = 0; g < quads; ++g)
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
@@ -428,11 +444,24 @@ __device__ __forceinline__ StripOut strip_mma(const AView& A, const BView& Bv, i
                     for (int i = 0; i < MT; ++i)
                         reinterpret_cast<float4*>(imgA + i * a_tile)[pc * 64 + lane] = A.get(m0 + 16 * i, kb, kend, pc * 64 + lane);
             }
-            for (int pc = 0; pc < pieces; ++pc)
+            if constexpr (FAST_B) {
+                const rsrc_t rb = Bv.rsrc();
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    reinterpret_cast<float4*>(imgB + t * b_tile)[pc * 64 + lane] = Bv.get(n0 + 16 * t, kb, kend, pc * 64 + lane);
+                for (int t = 0; t < NT; ++t) {
+                    DmaLane lb = Bv.lane0(n0 + 16 * t, kb, lane);
+                    for (int pc = 0; pc < pieces; ++pc) {
+                        blds16(rb, lb.voff, imgB + t * b_tile + pc * 1024);
+                        lb.voff += lb.step;
+                    }
+                }
+            } else {
+                for (int pc = 0; pc < pieces; ++pc)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        reinterpret_cast<float4*>(imgB + t * b_tile)[pc * 64 + lane] = Bv.get(n0 + 16 * t, kb, kend, pc * 64 + lane);
+            }
             QBM_STAMP(1);
+            if constexpr (FAST_A || FAST_B) vm_wait(0);
             QBM_STAMP(2);
             run(0, pieces);
         }
@@ -451,21 +480,21 @@ __device__ __forceinline__ StripOut strip_mma(const AView& A, const BView& Bv, i
             for (int r = 0; r < 4; ++r) red[(16 * i + (lane >> 4) * 4 + r) * RS + 16 * t + (lane & 15)] = acc[i][t][r];
     __syncthreads();
 
-    StripOut o;
-    o.valid = tid < 64 * MT * NT;
-    o.row = tid / (4 * NT);
-    o.cg = tid % (4 * NT);
-    o.sum = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (o.valid) {
-        const char* base = lds + (size_t)(o.row * RS + 4 * o.cg) * 4;
-        const float4 p0 = *reinterpret_cast<const float4*>(base);
-        const float4 p1 = *reinterpret_cast<const float4*>(base + wave_bytes);
-        const float4 p2 = *reinterpret_cast<const float4*>(base + 2 * (size_t)wave_bytes);
-        const float4 p3 = *reinterpret_cast<const float4*>(base + 3 * (size_t)wave_bytes);
-        o.sum.x = ((p0.x + p1.x) + p2.x) + p3.x;
-        o.sum.y = ((p0.y + p1.y) + p2.y) + p3.y;
-        o.sum.z = ((p0.z + p1.z) + p2.z) + p3.z;
-        o.sum.w = ((p0.w + p1.w) + p2.w) + p3.w;
+    StripOut<MT, NT> o;
+#pragma unroll
+    for (int p = 0; p < StripOut<MT, NT>::NP; ++p) {
+        o.sum[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (o.valid(p)) {
+            const char* base = lds + (size_t)(o.row(p) * RS + 4 * o.cg(p)) * 4;
+            const float4 p0 = *reinterpret_cast<const float4*>(base);
+            const float4 p1 = *reinterpret_cast<const float4*>(base + wave_bytes);
+            const float4 p2 = *reinterpret_cast<const float4*>(base + 2 * (size_t)wave_bytes);
+            const float4 p3 = *reinterpret_cast<const float4*>(base + 3 * (size_t)wave_bytes);
+            o.sum[p].x = ((p0.x + p1.x) + p2.x) + p3.x;
+            o.sum[p].y = ((p0.y + p1.y) + p2.y) + p3.y;
+            o.sum[p].z = ((p0.z + p1.z) + p2.z) + p3.z;
+            o.sum[p].w = ((p0.w + p1.w) + p2.w) + p3.w;
+        }
     }
     QBM_STAMP(4);
     __syncthreads();  // the partials are consumed: the caller may run another contraction on this LDS

@@ -28,11 +28,11 @@ __global__ __launch_bounds__(256) void k_h(const TA* v, const float* y, const fl
     using AV = typename std::conditional<sizeof(TA) == 1, ViewKContigU8, ViewKContig>::type;
     const AV A{v, V, B};
     const ViewCContig Bv{W, H, H, V};
-    const StripOut o = strip_mma<MT, NT, true>(A, Bv, m0, n0, V, lds, KP);
+    const auto o = strip_mma<MT, NT, true, true>(A, Bv, m0, n0, V, lds, KP);
     QBM_STAMP(5);
-    if (o.valid) {
-        const int i = m0 + o.row, j0 = n0 + 4 * o.cg;
-        const float sv[4] = {o.sum.x, o.sum.y, o.sum.z, o.sum.w};
+    if (o.valid(0)) {
+        const int i = m0 + o.row(0), j0 = n0 + 4 * o.cg(0);
+        const float sv[4] = {o.sum[0].x, o.sum[0].y, o.sum[0].z, o.sum[0].w};
         const float4 dv = *(const float4*)(d + j0);
         float cls[4] = {0, 0, 0, 0};
         float yv[10]; float4 uv[10];
