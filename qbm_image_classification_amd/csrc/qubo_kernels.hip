@@ -12,11 +12,17 @@ using namespace qbm;
 namespace {
 
 // ---------------------------------------------------------------------------------------------
-// One wavefront per chain (image b, read r).  Lane l keeps the local fields F_i and thresholds of
-// spins i = 64 t + l (t < NF) in registers; spin bits live in wave-uniform 64-bit masks.
-// Per spin: two v_readlane (field, threshold), one multiply, one compare; on a flip every lane
-// adds +-J[i, own spins] (one coalesced row read) -- the flip decision is wave-uniform, so there is
-// no divergence.  Uniforms come from Philox (row = chain id, col = spin), one draw id per sweep.
+// One wavefront per chain (image b, read r).  Lane l keeps the local field F_i, the threshold and the
+// state of spins i = 64 t + l (t < NF) in registers.
+//
+// The sweep is sequential in i by contract, but it is evaluated speculatively 64 spins at a time: all
+// lanes of a tile test their spin against the CURRENT fields at once (one multiply + compare), a ballot
+// finds the first lane that wants to flip; every lane before it keeps its state -- exactly what the
+// sequential sweep would have decided, because no earlier flip has touched their fields -- the flip is
+// applied (every lane adds +-J[i, own spins]: one coalesced row read, wave-uniform control flow), and
+// the test is repeated for the lanes behind it.  Cost per tile = (number of flips + 1) wave-wide steps
+// instead of 64 serial ones; results are bit-identical to the serial order.
+// Uniforms come from Philox (row = chain id, col = spin), one draw id per sweep.
 // ---------------------------------------------------------------------------------------------
 template <int NF>
 __global__ __launch_bounds__(256) void k_qubo_gibbs(const float* __restrict__ lin, const float* __restrict__ J,
@@ -29,25 +35,24 @@ __global__ __launch_bounds__(256) void k_qubo_gibbs(const float* __restrict__ li
     if (ch >= nchains) return;
     const int b = ch / R;
     float F[NF], thr[NF];
-    unsigned long long mask[NF];
+    bool st[NF];   // this lane's spin of tile t
 
     // start state s_i = (u < 0.5), draw id `offset`
 #pragma unroll
     for (int t = 0; t < NF; ++t) {
         const int i = 64 * t + lane;
-        bool s = false;
+        st[t] = false;
         F[t] = 0.f;
         if (i < n) {
             const f32x4 u = uniform4(seed, offset, (uint32_t)ch, (uint32_t)(i >> 2));
-            s = u[i & 3] < 0.5f;
+            st[t] = u[i & 3] < 0.5f;
             F[t] = lin[(long)b * n + i];
         }
-        mask[t] = __ballot(s);
     }
     // initial fields: + J[j, :] for set spins j ascending
 #pragma unroll
     for (int t = 0; t < NF; ++t) {
-        unsigned long long m = mask[t];
+        unsigned long long m = __ballot(st[t]);
         while (m) {
             const int j = 64 * t + __builtin_ctzll(m);
             m &= m - 1;
@@ -77,28 +82,30 @@ __global__ __launch_bounds__(256) void k_qubo_gibbs(const float* __restrict__ li
 #pragma unroll
         for (int t = 0; t < NF; ++t) {
             const int cnt = min(64, n - 64 * t);
-            for (int l = 0; l < cnt; ++l) {
-                const float Fi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, F[t]), l));
-                const float th = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, thr[t]), l));
-                const bool ns = (beta * Fi) < th;
-                const bool cur = (mask[t] >> l) & 1ull;
-                if (ns != cur) {
-                    const float sg = ns ? 1.0f : -1.0f;
-                    const float* Jr = J + (long)(64 * t + l) * n;
+            if (cnt <= 0) break;
+            unsigned long long pending = (cnt >= 64) ? ~0ull : ((1ull << cnt) - 1ull);  // spins of this tile not yet visited
+            while (true) {
+                const bool ns = (beta * F[t]) < thr[t];
+                const unsigned long long want = __ballot(ns != st[t]) & pending;
+                if (want == 0ull) break;
+                const int l = __builtin_ctzll(want);              // first spin that flips; the ones before it stay
+                const bool was = (__ballot(st[t]) >> l) & 1ull;
+                const float sg = was ? -1.0f : 1.0f;
+                const float* Jr = J + (long)(64 * t + l) * n;
 #pragma unroll
-                    for (int tt = 0; tt < NF; ++tt) {
-                        const int i = 64 * tt + lane;
-                        if (i < n) F[tt] = __builtin_fmaf(sg, Jr[i], F[tt]);
-                    }
-                    mask[t] ^= (1ull << l);
+                for (int tt = 0; tt < NF; ++tt) {
+                    const int i = 64 * tt + lane;
+                    if (i < n) F[tt] = __builtin_fmaf(sg, Jr[i], F[tt]);
                 }
+                if (lane == l) st[t] = !was;
+                pending = (l >= 63) ? 0ull : (pending & (~0ull << (l + 1)));
             }
         }
     }
 #pragma unroll
     for (int t = 0; t < NF; ++t) {
         const int i = 64 * t + lane;
-        if (i < n) states[(long)ch * n + i] = (uint8_t)((mask[t] >> lane) & 1ull);
+        if (i < n) states[(long)ch * n + i] = st[t] ? 1 : 0;
     }
 }
 

@@ -35,7 +35,8 @@
 #define QBM_STAMP(i)
 #endif
 // diagnostic builds may also define QBM_DIAG_MODE as an int expression: 1 = one vmcnt(0) before the MFMA loop
-// instead of the half-way counted wait, 3 = no MFMA loop.  0 in the product (the branches fold away).
+// instead of the half-way counted wait, 3 = no MFMA loop, 4 = no staging and no waits (the MFMA loop alone, on
+// whatever the LDS holds).  0 in the product (the branches fold away).
 #ifndef QBM_DIAG_MODE
 #define QBM_DIAG_MODE 0
 #endif
@@ -390,7 +391,7 @@ __device__ __forceinline__ StripOut<MT, NT> strip_mma(const AView& A, const BVie
             for (int t = 0; t < NT; ++t) lb[t] = Bv.lane0(n0 + 16 * t, kb, lane);
             const int half = (pieces + 1) >> 1;
             int issued_half = 0, issued = 0;
-            for (int pc = 0; pc < pieces; ++pc) {
+            for (int pc = 0; pc < (QBM_DIAG_MODE == 4 ? 0 : pieces); ++pc) {
                 if (!A8 || (pc & 3) == 0) {
 #pragma unroll
                     for (int i = 0; i < MT; ++i) {
@@ -414,11 +415,16 @@ __device__ __forceinline__ StripOut<MT, NT> strip_mma(const AView& A, const BVie
             // The compiler does not order a ds_read behind a pending LDS-DMA: the two halves of the MFMA
             // loop sit behind explicit vmcnt waits (counted for the first half, so that the second half of
             // the transfers lands under the first half of the MFMAs).
-            if (QBM_DIAG_MODE == 1) vm_wait(0); else vm_wait(issued - issued_half);
-            QBM_STAMP(2);
-            if (QBM_DIAG_MODE != 3) run(0, half);
-            vm_wait(0);
-            if (QBM_DIAG_MODE != 3) run(half, pieces);
+            if (QBM_DIAG_MODE == 4) {
+                QBM_STAMP(2);
+                run(0, pieces);
+            } else {
+                if (QBM_DIAG_MODE == 1) vm_wait(0); else vm_wait(issued - issued_half);
+                QBM_STAMP(2);
+                if (QBM_DIAG_MODE != 3) run(0, half);
+                vm_wait(0);
+                if (QBM_DIAG_MODE != 3) run(half, pieces);
+            }
         } else {
             // ---- at least one operand goes through registers (unaligned / ragged / synthesised)
             const int quads = (pieces + 3) >> 2;

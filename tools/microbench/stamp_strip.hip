@@ -90,6 +90,7 @@ int main()
     run<uint8_t>("u8 A, product path (half-way counted vmcnt)", 0);
     run<uint8_t>("u8 A, one vmcnt(0) before the MFMA loop", 1);
     run<uint8_t>("u8 A, no MFMA loop", 3);
+    run<uint8_t>("u8 A, MFMA loop alone (no staging, no waits)", 4);
     run<float>("fp32 A, product path", 0);
     return 0;
 }
