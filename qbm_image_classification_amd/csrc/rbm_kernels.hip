@@ -88,23 +88,26 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
     const int m0 = ms * 16 * MT, n0 = ns * 16 * NT;
     const typename KView<TA>::type A{reinterpret_cast<const TA*>(a.v), a.V, a.B};
     const ViewCContig Bv{a.W, a.H, a.H, a.V};
-    const auto o = strip_mma<MT, NT, FAST, FAST>(A, Bv, m0, n0, a.V, lds, a.KP);
+    // Everything of the epilogue that does not depend on the contraction is done BEFORE it -- bias and class
+    // term loads (unconditional, indices clamped, so that they are all in flight together), the class chain
+    // (classes c >= C enter it as fmaf(0, u, cls), which is exact) and the Philox draw -- so that it overlaps
+    // the LDS-DMA of the operands instead of sitting in the tail of the kernel.
+    using SO = StripOut<MT, NT>;
+    float dv[SO::NP][4], cls[SO::NP][4];
+    f32x4 uu[SO::NP];
 #pragma unroll
-    for (int op = 0; op < o.NP; ++op) {
-        if (!o.valid(op)) continue;
-        const int i = m0 + o.row(op), j0 = n0 + 4 * o.cg(op);
-        if (i >= a.B || j0 >= a.H) continue;
+    for (int op = 0; op < SO::NP; ++op) {
+        const int i = min(m0 + SO::row(op), a.B - 1), j0 = n0 + 4 * SO::cg(op);
         const bool vec = a.vecO && j0 + 3 < a.H;
-        const float sv[4] = {o.sum[op].x, o.sum[op].y, o.sum[op].z, o.sum[op].w};
-        // every load below is unconditional (indices clamped into range) so that they are all in flight
-        // together; classes c >= C enter the chain as fmaf(0, u, cls), which is exact
-        float dv[4], cls[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cls[op][e] = 0.f;
+        uu[op] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (vec) {
             const float4 t = *reinterpret_cast<const float4*>(a.d + j0);
-            dv[0] = t.x; dv[1] = t.y; dv[2] = t.z; dv[3] = t.w;
+            dv[op][0] = t.x; dv[op][1] = t.y; dv[op][2] = t.z; dv[op][3] = t.w;
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) dv[e] = a.d[min(j0 + e, a.H - 1)];
+            for (int e = 0; e < 4; ++e) dv[op][e] = a.d[min(j0 + e, a.H - 1)];
         }
         if (MODE == 0 && a.y) {
             float yv[CM];
@@ -119,29 +122,38 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
                 for (int c = 0; c < CM; ++c) uv[c] = *reinterpret_cast<const float4*>(a.U + (long)min(c, a.C - 1) * a.H + j0);
 #pragma unroll
                 for (int c = 0; c < CM; ++c) {
-                    cls[0] = __builtin_fmaf(yv[c], uv[c].x, cls[0]);
-                    cls[1] = __builtin_fmaf(yv[c], uv[c].y, cls[1]);
-                    cls[2] = __builtin_fmaf(yv[c], uv[c].z, cls[2]);
-                    cls[3] = __builtin_fmaf(yv[c], uv[c].w, cls[3]);
+                    cls[op][0] = __builtin_fmaf(yv[c], uv[c].x, cls[op][0]);
+                    cls[op][1] = __builtin_fmaf(yv[c], uv[c].y, cls[op][1]);
+                    cls[op][2] = __builtin_fmaf(yv[c], uv[c].z, cls[op][2]);
+                    cls[op][3] = __builtin_fmaf(yv[c], uv[c].w, cls[op][3]);
                 }
             } else {
 #pragma unroll
                 for (int c = 0; c < CM; ++c)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        cls[e] = __builtin_fmaf(yv[c], a.U[(long)min(c, a.C - 1) * a.H + min(j0 + e, a.H - 1)], cls[e]);
+                        cls[op][e] = __builtin_fmaf(yv[c], a.U[(long)min(c, a.C - 1) * a.H + min(j0 + e, a.H - 1)], cls[op][e]);
             }
         }
+        if (MODE == 0 && (a.s || a.s8))
+            uu[op] = uniform4(a.seed, a.offset, a.row0 + (uint32_t)(m0 + SO::row(op)), (uint32_t)(j0 >> 2));
+    }
+    const auto o = strip_mma<MT, NT, FAST, FAST>(A, Bv, m0, n0, a.V, lds, a.KP);
+#pragma unroll
+    for (int op = 0; op < o.NP; ++op) {
+        if (!o.valid(op)) continue;
+        const int i = m0 + o.row(op), j0 = n0 + 4 * o.cg(op);
+        if (i >= a.B || j0 >= a.H) continue;
+        const bool vec = a.vecO && j0 + 3 < a.H;
+        const float sv[4] = {o.sum[op].x, o.sum[op].y, o.sum[op].z, o.sum[op].w};
         float pv[4], hv[4];
-        f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (MODE == 0 && (a.s || a.s8)) u = uniform4(a.seed, a.offset, a.row0 + (uint32_t)i, (uint32_t)(j0 >> 2));
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float x = sv[e] + dv[e];
+            float x = sv[e] + dv[op][e];
             if (MODE == 0) {
-                if (a.y) x = x + cls[e];
+                if (a.y) x = x + cls[op][e];
                 pv[e] = det_sigmoid(x);
-                hv[e] = (pv[e] > u[e]) ? 1.f : 0.f;
+                hv[e] = (pv[e] > uu[op][e]) ? 1.f : 0.f;
             } else {
                 pv[e] = x; hv[e] = 0.f;
             }
@@ -272,6 +284,23 @@ __global__ __launch_bounds__(256) void k_visible(VisibleArgs a)
     const int m0 = ms * 16 * MT, n0 = ns * 16 * NT;
     const typename KView<TA>::type A{reinterpret_cast<const TA*>(a.h), a.H, a.B};
     const ViewKContig Bv{a.W, a.H, a.V};
+    // bias loads and the Philox draw do not depend on the contraction: issue them before it
+    using SO = StripOut<MT, NT>;
+    float bv[SO::NP][4];
+    f32x4 uu[SO::NP];
+#pragma unroll
+    for (int op = 0; op < SO::NP; ++op) {
+        const int k0 = n0 + 4 * SO::cg(op);
+        if (a.vecO && k0 + 3 < a.V) {
+            const float4 t = *reinterpret_cast<const float4*>(a.b + k0);
+            bv[op][0] = t.x; bv[op][1] = t.y; bv[op][2] = t.z; bv[op][3] = t.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[op][e] = a.b[min(k0 + e, a.V - 1)];
+        }
+        uu[op] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.s || a.s8) uu[op] = uniform4(a.seed, a.offset, a.row0 + (uint32_t)(m0 + SO::row(op)), (uint32_t)(k0 >> 2));
+    }
     const auto o = strip_mma<MT, NT, FAST, FAST>(A, Bv, m0, n0, a.H, lds, a.KP);
 #pragma unroll
     for (int op = 0; op < o.NP; ++op) {
@@ -280,21 +309,11 @@ __global__ __launch_bounds__(256) void k_visible(VisibleArgs a)
         if (i >= a.B || k0 >= a.V) continue;
         const bool vec = a.vecO && k0 + 3 < a.V;
         const float sv[4] = {o.sum[op].x, o.sum[op].y, o.sum[op].z, o.sum[op].w};
-        float bv[4];
-        if (vec) {
-            const float4 t = *reinterpret_cast<const float4*>(a.b + k0);
-            bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bv[e] = a.b[min(k0 + e, a.V - 1)];
-        }
         float pv[4], vv[4];
-        f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (a.s || a.s8) u = uniform4(a.seed, a.offset, a.row0 + (uint32_t)i, (uint32_t)(k0 >> 2));
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            pv[e] = det_sigmoid(sv[e] + bv[e]);
-            vv[e] = (pv[e] > u[e]) ? 1.f : 0.f;
+            pv[e] = det_sigmoid(sv[e] + bv[op][e]);
+            vv[e] = (pv[e] > uu[op][e]) ? 1.f : 0.f;
         }
         const long off = (long)i * a.V + k0;
         if (vec) {
