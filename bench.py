@@ -186,13 +186,21 @@ def main():
                 4.0 * B * V * H + 4.0 * B * NC * H, 1),
         }
         timed = {k: time_kernel(f) for k, (f, _, _) in kernels.items()}
-        dom = max(timed, key=lambda k: timed[k] * kernels[k][2])
+        dom = max(timed, key=lambda k: timed[k] * kernels[k][2])   # most time per CD-1 step
+        # HBM bytes per launch of that kernel from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate
+        # rocprofv3 --pmc passes: tools/gpu_pmc_traffic.sh -> profiles/r01_pmc_traffic.json); null if absent
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = json.load(f)["kernels"][dom.split(" ")[0]]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         fl = kernels[dom][1]
         ach = fl / timed[dom] / 1e12
         alg_bytes = 4.0 * B * V + 8.0 * (V * H + V + H + NC * H + NC) + 4.0 * B    # SURVEY.md 8.D, per CD-1 step
         roofline = {
             "bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
             "avg_launch_us": round(timed[dom] * 1e6, 3),
             "all_kernels_us": {k: round(t * 1e6, 3) for k, t in timed.items()},
             "step_flops": (4 * K_CD + 6) * B * V * H + (4 * K_CD + 6) * B * NC * H,
@@ -222,10 +230,25 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cores() -> int:
+    """CPU cores this process may actually use: the cgroup quota if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(budget_s: float):
     """Same CD-1 step (same shapes, same Philox stream) on the oracle; `cores` = OpenMP threads used."""
     import numpy as np
 
+    cores = usable_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)      # before libgomp starts: one thread per usable core
+    os.environ.setdefault("OMP_WAIT_POLICY", "ACTIVE")
     from oracle import qbm_oracle as orc
 
     orc.build()
@@ -250,7 +273,7 @@ def cpu_baseline(budget_s: float):
         one(n + 1)
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": round(B * K_CD * n / dt, 1), "unit": "samples/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
+    return {"value": round(B * K_CD * n / dt, 1), "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"{n} CD-1 steps of the same 784x512, B=256 workload in {dt:.1f} s (oracle/qbm_oracle.c, OpenMP)",
             "ms_per_step": round(dt / n * 1e3, 3)}
 
