@@ -41,12 +41,19 @@ def parse():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--graph", type=int, default=8, help="steps captured per hipGraph (0 = eager launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="run the data-parallel code path (gradient all-reduce + separate update) even with one rank")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
 def main():
     args = parse()
+    # stdout carries exactly ONE JSON line: libraries that print banners there (RCCL prints its version on
+    # stdout at init) are diverted to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -58,8 +65,11 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
-    if world > 1:
+    dp = world > 1 or args.force_dp
+    if dp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if "MASTER_ADDR" not in os.environ:      # --force-dp without torchrun: a one-rank group
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
     from qbm_image_classification_amd import _lib
@@ -95,7 +105,7 @@ def main():
         """one CD-1 update on resident minibatch i % NB"""
         j = i % NB
         off = 4 * i
-        if world == 1:
+        if not dp:
             check(lib.qbm_rbm_cd_step(C.byref(ps), C.byref(gs), ptr(data_v[j]), QBM_U8, ptr(data_y[j]), B, K_CD, 42, off,
                                       row_base, None, None, C.byref(cws), 1, lr, factor, global_B, sparse, stream),
                   "qbm_rbm_cd_step")
@@ -110,7 +120,7 @@ def main():
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     graphs = None
-    if args.graph > 0 and world == 1:
+    if args.graph > 0 and not dp:
         # S consecutive steps (S resident minibatches) per hipGraph: amortises host launch cost
         S = args.graph
         for i in range(S):                                           # eager warm-up of every code path
@@ -134,7 +144,7 @@ def main():
                 step(i, cur())
 
     def barrier():
-        if world > 1:
+        if dp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -144,7 +154,7 @@ def main():
     run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -221,12 +231,13 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "ClassificationRBM 784v x 512h, C=10, CD-1, batch 256 per GPU (BASELINE.json configs[3] shape; "
                                    "global batch 256*N, RCCL all-reduce of the flat gradient per step when N>1)",
-                       "batch_per_gpu": B, "cd_k": K_CD, "launch": f"hipGraph x{graphs[1]} steps" if graphs else "eager"},
+                       "batch_per_gpu": B, "cd_k": K_CD, "launch": f"hipGraph x{graphs[1]} steps" if graphs else "eager",
+                       "parallelism": f"dp{world}" + (" (forced data-parallel path)" if args.force_dp and world == 1 else "")},
             "visible_unit_updates_per_sec": round(value * V, 1),
             "roofline": roofline, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
-    if world > 1:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if dp:
         dist.destroy_process_group()
 
 

@@ -336,38 +336,42 @@ __global__ __launch_bounds__(256) void k_visible(VisibleArgs a)
 //   -F_y = c_y + sum_j log(1 + exp(pre_j + U_yj));   p_c = 1 / sum_d exp(-(-F_c) + (-F_d))
 // One wavefront per row, wave tree [T] over j.
 // ---------------------------------------------------------------------------------------------
+// One workgroup per row: wave w evaluates the classes c = w, w+4, ... (each class is one wave tree [T] over j,
+// exactly as if a single wave had done it), the -F values meet in LDS and lane 0 of wave 0 forms p(y|x).
 template <int CM>
 __global__ __launch_bounds__(256) void k_free_energy(const float* __restrict__ pre, const float* __restrict__ U,
                                                      const float* __restrict__ cb, float* __restrict__ negF,
                                                      float* __restrict__ p_out, int B, int H, int C)
 {
+    __shared__ float nf_s[QBM_MAX_CLASSES + 1];
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= B) return;
-    float nf[CM], cbv[CM];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = blockIdx.x;
+    constexpr int CW = (CM + 3) / 4;   // classes per wave
+    float nf[CW], cbv[CW];
 #pragma unroll
-    for (int c = 0; c < CM; ++c) { nf[c] = 0.f; cbv[c] = cb[min(c, C - 1)]; }
+    for (int t = 0; t < CW; ++t) { nf[t] = 0.f; cbv[t] = cb[min(w + 4 * t, C - 1)]; }
     for (int j = lane; j < H; j += kWave) {
         const float pr = pre[(long)i * H + j];
-        float uv[CM];
+        float uv[CW];
 #pragma unroll
-        for (int c = 0; c < CM; ++c) uv[c] = U[(long)min(c, C - 1) * H + j];
+        for (int t = 0; t < CW; ++t) uv[t] = U[(long)min(w + 4 * t, C - 1) * H + j];
 #pragma unroll
-        for (int c = 0; c < CM; ++c) nf[c] = nf[c] + det_softplus(pr + uv[c]);
+        for (int t = 0; t < CW; ++t) nf[t] = nf[t] + det_softplus(pr + uv[t]);
     }
 #pragma unroll
-    for (int c = 0; c < CM; ++c) nf[c] = cbv[c] + wave_butterfly_sum(nf[c]);
-    if (lane != 0) return;
-#pragma unroll
-    for (int c = 0; c < CM; ++c) {
-        if (c < C) {
-            if (negF) negF[(long)i * C + c] = nf[c];
-            float s = 0.f;
-#pragma unroll
-            for (int dd = 0; dd < CM; ++dd)
-                if (dd < C) s = s + det_expf((-1.0f * nf[c]) + nf[dd]);
-            if (p_out) p_out[(long)i * C + c] = 1.0f / s;
-        }
+    for (int t = 0; t < CW; ++t) {
+        const float v = cbv[t] + wave_butterfly_sum(nf[t]);
+        if (lane == 0 && w + 4 * t < C) nf_s[w + 4 * t] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int c = 0; c < C; ++c) {
+        const float nfc = nf_s[c];
+        if (negF) negF[(long)i * C + c] = nfc;
+        float s = 0.f;
+        for (int dd = 0; dd < C; ++dd) s = s + det_expf((-1.0f * nfc) + nf_s[dd]);
+        if (p_out) p_out[(long)i * C + c] = 1.0f / s;
     }
 }
 
@@ -400,35 +404,39 @@ __global__ __launch_bounds__(256) void k_disc_terms(const float* __restrict__ pr
 // A-5, class-weight / class-bias part (:113-115, :125, :132, :136):
 //   gU[c,j] = (onehot^T.pos)[c,j] - sum_i o_icj p_ic      (first term already in gU, from k_grad)
 //   gc[c]   = sum_i onehot_ic - sum_i p_ic
-// Batch sums are quartered chains [Q].  One thread per (c, j); thread (c, 0) also does gc[c].
+// Batch sums are quartered chains [Q].  Workgroup = (class c, 64 hidden columns): lane = column, wave q walks
+// batch quarter q, the four partials meet in LDS.  The workgroup of columns 0..63 also does gc[c] (lane 0).
 __global__ __launch_bounds__(256) void k_disc_class_grad(const float* __restrict__ pre, const float* __restrict__ U,
                                                          const float* __restrict__ p, const int* __restrict__ labels,
                                                          float* __restrict__ gU, float* __restrict__ gc, int B, int H,
                                                          int C)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= C * H) return;
-    const int c = idx / H, j = idx % H;
+    __shared__ float part[4][3][64];
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nJ = (H + 63) / 64;
+    const int c = blockIdx.x / nJ, j = (blockIdx.x % nJ) * 64 + lane;
+    const int jj = min(j, H - 1);
     const int Kq = quarter_len(B);
-    const float u = U[idx];
-    float part[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int q = 0; q < 4; ++q) {
-        const int i1 = min(B, (q + 1) * Kq);
-        float a = 0.f;
-        for (int i = q * Kq; i < i1; ++i) a = __builtin_fmaf(1.0f, det_sigmoid(pre[(long)i * H + j] + u) * p[(long)i * C + c], a);
-        part[q] = a;
+    const int i0 = q * Kq, i1 = min(B, i0 + Kq);
+    const float u = U[(long)c * H + jj];
+    float a = 0.f, s0 = 0.f, s1 = 0.f;
+#pragma unroll 4
+    for (int i = i0; i < i1; ++i) {
+        const float pc = p[(long)i * C + c];
+        a = __builtin_fmaf(1.0f, det_sigmoid(pre[(long)i * H + jj] + u) * pc, a);
+        s0 = __builtin_fmaf(1.0f, (labels[i] == c) ? 1.f : 0.f, s0);
+        s1 = __builtin_fmaf(1.0f, pc, s1);
     }
-    gU[idx] = gU[idx] - (((part[0] + part[1]) + part[2]) + part[3]);
-    if (j == 0 && gc) {
-        float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int q = 0; q < 4; ++q) {
-            const int i1 = min(B, (q + 1) * Kq);
-            for (int i = q * Kq; i < i1; ++i) {
-                s0[q] = __builtin_fmaf(1.0f, (labels[i] == c) ? 1.f : 0.f, s0[q]);
-                s1[q] = __builtin_fmaf(1.0f, p[(long)i * C + c], s1[q]);
-            }
-        }
-        gc[c] = (((s0[0] + s0[1]) + s0[2]) + s0[3]) - (((s1[0] + s1[1]) + s1[2]) + s1[3]);
+    part[q][0][lane] = a; part[q][1][lane] = s0; part[q][2][lane] = s1;
+    __syncthreads();
+    if (q != 0) return;
+    const float ta = ((part[0][0][lane] + part[1][0][lane]) + part[2][0][lane]) + part[3][0][lane];
+    if (j < H) gU[(long)c * H + j] = gU[(long)c * H + j] - ta;
+    if (gc && blockIdx.x % nJ == 0 && lane == 0) {
+        const float t0 = ((part[0][1][0] + part[1][1][0]) + part[2][1][0]) + part[3][1][0];
+        const float t1 = ((part[0][2][0] + part[1][2][0]) + part[2][2][0]) + part[3][2][0];
+        gc[c] = t0 - t1;
     }
 }
 
@@ -879,7 +887,7 @@ int qbm_rbm_free_energy(const qbm_rbm_params* P, const float* x, int B, float* p
     if (!x || !pre_ws || (!neg_free_energy && !p_y_given_x)) return fail(QBM_ERR_ARG, "free_energy: null buffer");
     if (int rc = launch_hidden(P, x, QBM_F32, nullptr, B, pre_ws, nullptr, nullptr, 1, 0, 0, 0, (hipStream_t)stream)) return rc;
 #define QBM_L(CM)                                                                                               \
-    hipLaunchKernelGGL((k_free_energy<CM>), dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, pre_ws, P->U,   \
+    hipLaunchKernelGGL((k_free_energy<CM>), dim3(B), dim3(256), 0, (hipStream_t)stream, pre_ws, P->U,             \
                        P->c, neg_free_energy, p_y_given_x, B, P->H, P->C)
     QBM_DISPATCH_CM(P->C, QBM_L);
 #undef QBM_L
@@ -906,8 +914,8 @@ int qbm_rbm_disc_class_grad(const qbm_rbm_params* P, const float* pre, const flo
     if (int rc = check_params(P)) return rc;
     if (B <= 0) return B == 0 ? QBM_OK : fail(QBM_ERR_ARG, "B < 0");
     if (!pre || !p_y || !labels || !gU) return fail(QBM_ERR_ARG, "disc_class_grad: null buffer");
-    const int n = P->C * P->H;
-    hipLaunchKernelGGL(k_disc_class_grad, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, pre, P->U, p_y,
+    const int n = P->C * ((P->H + 63) / 64);
+    hipLaunchKernelGGL(k_disc_class_grad, dim3(n), dim3(256), 0, (hipStream_t)stream, pre, P->U, p_y,
                        labels, gU, gc, B, P->H, P->C);
     QBM_CHECK_LAUNCH("k_disc_class_grad");
     return QBM_OK;
