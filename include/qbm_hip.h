@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QBM_ABI_VERSION 2
+#define QBM_ABI_VERSION 3
 #define QBM_MAX_CLASSES 15 /* class rows + the bias row share one 16-row gradient tile */
 #define QBM_MAX_QUBO_VARS 1024
 
@@ -181,6 +181,7 @@ typedef struct {
     float* pos;    /* [B,H] */
     float* neg;    /* [B,H] */
     float* onehot; /* [B,C] */
+    float* cls_neg; /* [C,H] sum_i sigma(pre_i + U_c) p(c|x_i), the subtrahend of the class-weight gradient */
 } qbm_rbm_disc_workspace;
 
 /* ClassificationRBM.discriminative_training, src/ClassificationRBM.py:101-146 without the host-side

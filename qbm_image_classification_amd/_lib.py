@@ -8,7 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libqbm_hip.so")
 
-QBM_ABI_VERSION = 2
+QBM_ABI_VERSION = 3
 QBM_MAX_CLASSES = 15
 QBM_F32, QBM_U8 = 0, 1
 
@@ -31,7 +31,8 @@ class CdWorkspace(C.Structure):
 
 
 class DiscWorkspace(C.Structure):
-    _fields_ = [("pre", C.c_void_p), ("pos", C.c_void_p), ("neg", C.c_void_p), ("onehot", C.c_void_p)]
+    _fields_ = [("pre", C.c_void_p), ("pos", C.c_void_p), ("neg", C.c_void_p), ("onehot", C.c_void_p),
+                ("cls_neg", C.c_void_p)]
 
 
 _p = C.c_void_p

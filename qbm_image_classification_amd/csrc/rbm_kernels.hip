@@ -336,42 +336,63 @@ __global__ __launch_bounds__(256) void k_visible(VisibleArgs a)
 //   -F_y = c_y + sum_j log(1 + exp(pre_j + U_yj));   p_c = 1 / sum_d exp(-(-F_c) + (-F_d))
 // One wavefront per row, wave tree [T] over j.
 // ---------------------------------------------------------------------------------------------
-// One workgroup per row: wave w evaluates the classes c = w, w+4, ... (each class is one wave tree [T] over j,
-// exactly as if a single wave had done it), the -F values meet in LDS and lane 0 of wave 0 forms p(y|x).
+// One workgroup per row, one wave per class (blockDim = 64 C): wave c does the wave tree [T] over j for class c,
+// the -F values meet in LDS, thread (c, d) forms exp(F_c - F_d) and thread c adds them up in d order -> p(y|x).
+// With `pos` set, the workgroup goes on to the elementwise stage of discriminative_training for its row
+// (k_disc_terms below, same operation order) while p is still in LDS.
 template <int CM>
-__global__ __launch_bounds__(256) void k_free_energy(const float* __restrict__ pre, const float* __restrict__ U,
-                                                     const float* __restrict__ cb, float* __restrict__ negF,
-                                                     float* __restrict__ p_out, int B, int H, int C)
+__global__ __launch_bounds__(64 * CM) void k_free_energy(const float* __restrict__ pre, const float* __restrict__ U,
+                                                         const float* __restrict__ cb, float* __restrict__ negF,
+                                                         float* __restrict__ p_out, int B, int H, int C,
+                                                         const int* __restrict__ labels, float* __restrict__ pos,
+                                                         float* __restrict__ neg, float* __restrict__ onehot)
 {
-    __shared__ float nf_s[QBM_MAX_CLASSES + 1];
+    __shared__ float nf_s[CM + 1], p_s[CM + 1];
+    __shared__ float e_s[CM * CM];
     const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = class
     const int i = blockIdx.x;
-    constexpr int CW = (CM + 3) / 4;   // classes per wave
-    float nf[CW], cbv[CW];
-#pragma unroll
-    for (int t = 0; t < CW; ++t) { nf[t] = 0.f; cbv[t] = cb[min(w + 4 * t, C - 1)]; }
-    for (int j = lane; j < H; j += kWave) {
-        const float pr = pre[(long)i * H + j];
-        float uv[CW];
-#pragma unroll
-        for (int t = 0; t < CW; ++t) uv[t] = U[(long)min(w + 4 * t, C - 1) * H + j];
-#pragma unroll
-        for (int t = 0; t < CW; ++t) nf[t] = nf[t] + det_softplus(pr + uv[t]);
-    }
-#pragma unroll
-    for (int t = 0; t < CW; ++t) {
-        const float v = cbv[t] + wave_butterfly_sum(nf[t]);
-        if (lane == 0 && w + 4 * t < C) nf_s[w + 4 * t] = v;
+    {
+        float nf = 0.f;
+        const float cbv = cb[w];
+        const float* prow = pre + (long)i * H;
+        const float* urow = U + (long)w * H;
+        for (int j = lane; j < H; j += kWave) nf = nf + det_softplus(prow[j] + urow[j]);
+        const float v = cbv + wave_butterfly_sum(nf);
+        if (lane == 0) nf_s[w] = v;
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    for (int c = 0; c < C; ++c) {
-        const float nfc = nf_s[c];
-        if (negF) negF[(long)i * C + c] = nfc;
+    {
+        const int c = threadIdx.x / CM, dd = threadIdx.x % CM;
+        if (c < C && dd < C) e_s[c * CM + dd] = det_expf((-1.0f * nf_s[c]) + nf_s[dd]);
+    }
+    __syncthreads();
+    if (threadIdx.x < C) {
+        const int c = threadIdx.x;
         float s = 0.f;
-        for (int dd = 0; dd < C; ++dd) s = s + det_expf((-1.0f * nfc) + nf_s[dd]);
-        if (p_out) p_out[(long)i * C + c] = 1.0f / s;
+        for (int dd = 0; dd < C; ++dd) s = s + e_s[c * CM + dd];
+        const float pc = 1.0f / s;
+        p_s[c] = pc;
+        if (negF) negF[(long)i * C + c] = nf_s[c];
+        if (p_out) p_out[(long)i * C + c] = pc;
+    }
+    if (!pos) return;
+    __syncthreads();
+    const int lab = labels[i];
+    if (threadIdx.x < C && onehot) onehot[(long)i * C + threadIdx.x] = ((int)threadIdx.x == lab) ? 1.f : 0.f;
+    for (int j = threadIdx.x; j < H; j += blockDim.x) {
+        const float pr = pre[(long)i * H + j];
+        float ng = 0.f, ps = 0.f;
+#pragma unroll
+        for (int c = 0; c < CM; ++c) {
+            if (c < C) {
+                const float o = det_sigmoid(pr + U[(long)c * H + j]);
+                ps = (c == lab) ? o : ps;
+                ng = ng + o * p_s[c];
+            }
+        }
+        pos[(long)i * H + j] = ps;
+        neg[(long)i * H + j] = ng;
     }
 }
 
@@ -401,43 +422,86 @@ __global__ __launch_bounds__(256) void k_disc_terms(const float* __restrict__ pr
     neg[idx] = ng;
 }
 
+// theta += ((factor * g) * lr) / bs, then - sparse for the biases (src/ClassificationRBM.py:88-99)
+struct StepScale { float lr, factor, bs, sparse; };
+__device__ __forceinline__ float upd_s(float th, float g, const StepScale& k, bool sparse)
+{
+    float t = k.factor * g;
+    t = t * k.lr;
+    t = t / k.bs;
+    th = th + t;
+    return sparse ? th - k.sparse : th;
+}
+
 // A-5, class-weight / class-bias part (:113-115, :125, :132, :136):
-//   gU[c,j] = (onehot^T.pos)[c,j] - sum_i o_icj p_ic      (first term already in gU, from k_grad)
+//   gU[c,j] = (onehot^T.pos)[c,j] - sum_i o_icj p_ic      (first term: k_grad, which subtracts `usub` written here)
 //   gc[c]   = sum_i onehot_ic - sum_i p_ic
-// Batch sums are quartered chains [Q].  Workgroup = (class c, 64 hidden columns): lane = column, wave q walks
-// batch quarter q, the four partials meet in LDS.  The workgroup of columns 0..63 also does gc[c] (lane 0).
+// Batch sums are quartered chains [Q].  Workgroup = (class c, 16 hidden columns): the 256 threads evaluate the
+// products o*p of 256 batch rows x 16 columns into LDS, then thread (quarter q, column) adds its quarter's rows in
+// order.  The workgroup of columns 0..15 also does gc[c]; with `uc` / `ub` set it applies the class-bias update and
+// the gradient-free visible-bias update (:138: grad 0, sparsity constant still applied).
 __global__ __launch_bounds__(256) void k_disc_class_grad(const float* __restrict__ pre, const float* __restrict__ U,
                                                          const float* __restrict__ p, const int* __restrict__ labels,
-                                                         float* __restrict__ gU, float* __restrict__ gc, int B, int H,
-                                                         int C)
+                                                         float* __restrict__ usub, float* __restrict__ gU,
+                                                         float* __restrict__ gc, float* __restrict__ uc,
+                                                         float* __restrict__ ub, StepScale sc, int B, int H, int C, int V)
 {
-    __shared__ float part[4][3][64];
-    const int lane = threadIdx.x & 63;
-    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nJ = (H + 63) / 64;
-    const int c = blockIdx.x / nJ, j = (blockIdx.x % nJ) * 64 + lane;
-    const int jj = min(j, H - 1);
+    __shared__ float t_s[256][17];
+    __shared__ float pc_s[256], oh_s[256];
+    __shared__ float part[4][18];
+    const int nJ = (H + 15) / 16;
+    const int c = blockIdx.x / nJ, jb = blockIdx.x % nJ;
+    const int col = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    const int j = jb * 16 + col, jj = min(j, H - 1);
     const int Kq = quarter_len(B);
-    const int i0 = q * Kq, i1 = min(B, i0 + Kq);
     const float u = U[(long)c * H + jj];
-    float a = 0.f, s0 = 0.f, s1 = 0.f;
-#pragma unroll 4
-    for (int i = i0; i < i1; ++i) {
-        const float pc = p[(long)i * C + c];
-        a = __builtin_fmaf(1.0f, det_sigmoid(pre[(long)i * H + jj] + u) * pc, a);
-        s0 = __builtin_fmaf(1.0f, (labels[i] == c) ? 1.f : 0.f, s0);
-        s1 = __builtin_fmaf(1.0f, pc, s1);
+    const bool chain = threadIdx.x < 64;                        // thread (q, col): the ordered sum of quarter q
+    const bool side = threadIdx.x >= 64 && threadIdx.x < 72;    // threads 64..67: sum onehot; 68..71: sum p
+    const int q = chain ? (int)(threadIdx.x >> 4) : (int)(threadIdx.x & 3);
+    const int lo = q * Kq, hi = min(B, lo + Kq);
+    float acc = 0.f;
+    for (int r0 = 0; r0 < B; r0 += 256) {
+        const int nr = min(256, B - r0);
+        float pr[16], pcv[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int i = min(r0 + slot + 16 * t, B - 1);
+            pr[t] = pre[(long)i * H + jj];
+            pcv[t] = p[(long)i * C + c];
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) t_s[slot + 16 * t][col] = det_sigmoid(pr[t] + u) * pcv[t];
+        if (threadIdx.x < nr) {
+            pc_s[threadIdx.x] = p[(long)(r0 + threadIdx.x) * C + c];
+            oh_s[threadIdx.x] = (labels[r0 + threadIdx.x] == c) ? 1.f : 0.f;
+        }
+        __syncthreads();
+        const int a0 = max(lo, r0) - r0, a1 = min(hi, r0 + nr) - r0;
+        if (chain) {
+            for (int i = a0; i < a1; ++i) acc = __builtin_fmaf(1.0f, t_s[i][col], acc);
+        } else if (side) {
+            const float* src = threadIdx.x < 68 ? oh_s : pc_s;
+            for (int i = a0; i < a1; ++i) acc = __builtin_fmaf(1.0f, src[i], acc);
+        }
+        __syncthreads();
     }
-    part[q][0][lane] = a; part[q][1][lane] = s0; part[q][2][lane] = s1;
+    if (chain) part[q][col] = acc;
+    if (side) part[q][threadIdx.x < 68 ? 16 : 17] = acc;
     __syncthreads();
-    if (q != 0) return;
-    const float ta = ((part[0][0][lane] + part[1][0][lane]) + part[2][0][lane]) + part[3][0][lane];
-    if (j < H) gU[(long)c * H + j] = gU[(long)c * H + j] - ta;
-    if (gc && blockIdx.x % nJ == 0 && lane == 0) {
-        const float t0 = ((part[0][1][0] + part[1][1][0]) + part[2][1][0]) + part[3][1][0];
-        const float t1 = ((part[0][2][0] + part[1][2][0]) + part[2][2][0]) + part[3][2][0];
-        gc[c] = t0 - t1;
+    if (threadIdx.x < 16 && j < H) {
+        const float ta = ((part[0][col] + part[1][col]) + part[2][col]) + part[3][col];
+        if (usub) usub[(long)c * H + j] = ta;
+        if (gU) gU[(long)c * H + j] = gU[(long)c * H + j] - ta;
     }
+    if (jb == 0 && threadIdx.x == 0) {
+        const float t0 = ((part[0][16] + part[1][16]) + part[2][16]) + part[3][16];
+        const float t1 = ((part[0][17] + part[1][17]) + part[2][17]) + part[3][17];
+        const float g = t0 - t1;
+        if (gc) gc[c] = g;
+        if (uc) uc[c] = upd_s(uc[c], g, sc, true);
+    }
+    if (ub)
+        for (int m = blockIdx.x * 256 + threadIdx.x; m < V; m += gridDim.x * 256) ub[m] = upd_s(ub[m], 0.f, sc, true);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -476,6 +540,7 @@ struct GradArgs {
     int KP;
     int nU, nB, nC;                              // workgroups of kind U, B, C (they precede kind W)
     bool vecO;
+    const float* gUsub;                          // non-null: class-weight gradient = (phase0 - phase1) - gUsub
 };
 
 __device__ __forceinline__ float upd(float th, float g, const GradArgs& a, bool sparse)
@@ -512,8 +577,9 @@ __global__ __launch_bounds__(256) void k_grad(GradArgs a)
                 if (n >= a.H) break;
                 if (row < a.C) {
                     const long off = (long)row * a.H + n;
-                    if (a.gU) a.gU[off] = g[e];
-                    if (a.uU) a.uU[off] = upd(a.uU[off], g[e], a, false);
+                    const float gu = a.gUsub ? g[e] - a.gUsub[off] : g[e];
+                    if (a.gU) a.gU[off] = gu;
+                    if (a.uU) a.uU[off] = upd(a.uU[off], gu, a, false);
                 } else {
                     if (a.gd) a.gd[n] = g[e];
                     if (a.ud) a.ud[n] = upd(a.ud[n], g[e], a, true);
@@ -764,7 +830,7 @@ int launch_visible(const qbm_rbm_params* P, const void* h, int h_dtype, int B, f
 template <class T0, class T1>
 int launch_grad_t(int V, int H, int C, int B, const void* A0, const float* Y0, const float* P0, const void* A1,
                   const float* Y1, const float* P1, const qbm_rbm_grads* G, float* W_fused, const qbm_rbm_params* aux_fused,
-                  float lr, float factor, float bs, float sparse, hipStream_t st)
+                  float lr, float factor, float bs, float sparse, hipStream_t st, const float* gU_sub)
 {
     constexpr int MT = G_MT, NT = G_NT;
     const int nM = (V + 16 * MT - 1) / (16 * MT), nN = (H + 16 * NT - 1) / (16 * NT);
@@ -775,7 +841,7 @@ int launch_grad_t(int V, int H, int C, int B, const void* A0, const float* Y0, c
                aux_fused ? aux_fused->U : nullptr, aux_fused ? aux_fused->c : nullptr,
                lr, factor, bs, sparse, B, V, H, C, panel_for<MT, NT, 4>(B),
                nN, want_b ? nM : 0, want_c ? (C + 16 * NT - 1) / (16 * NT) : 0,
-               (H % 4 == 0) && (!G->gW || aligned16(G->gW)) && (!W_fused || aligned16(W_fused))};
+               (H % 4 == 0) && (!G->gW || aligned16(G->gW)) && (!W_fused || aligned16(W_fused)), gU_sub};
     const bool fast = (B % 16 == 0) && (V % 16 == 0) && (H % 4 == 0) && aligned16(A0) && aligned16(A1) && aligned16(P0) &&
                       aligned16(P1) && small2g((long)B * V, 4) && small2g((long)B * H, 4);
     const int grid = a.nU + a.nB + a.nC + nM * nN;
@@ -793,10 +859,10 @@ int launch_grad_t(int V, int H, int C, int B, const void* A0, const float* Y0, c
 
 int launch_grad(int V, int H, int C, int B, const void* A0, int d0, const float* Y0, const float* P0, const void* A1, int d1,
                 const float* Y1, const float* P1, const qbm_rbm_grads* G, float* W_fused, const qbm_rbm_params* aux_fused,
-                float lr, float factor, float bs, float sparse, hipStream_t st)
+                float lr, float factor, float bs, float sparse, hipStream_t st, const float* gU_sub = nullptr)
 {
     if (C + 1 > 16) return fail(QBM_ERR_ARG, "two_phase_grad: at most 15 classes (class rows + the bias row share one 16-row tile)");
-#define QBM_G(T0, T1) launch_grad_t<T0, T1>(V, H, C, B, A0, Y0, P0, A1, Y1, P1, G, W_fused, aux_fused, lr, factor, bs, sparse, st)
+#define QBM_G(T0, T1) launch_grad_t<T0, T1>(V, H, C, B, A0, Y0, P0, A1, Y1, P1, G, W_fused, aux_fused, lr, factor, bs, sparse, st, gU_sub)
     if (d0 == QBM_U8) return d1 == QBM_U8 ? QBM_G(uint8_t, uint8_t) : QBM_G(uint8_t, float);
     return d1 == QBM_U8 ? QBM_G(float, uint8_t) : QBM_G(float, float);
 #undef QBM_G
@@ -887,8 +953,9 @@ int qbm_rbm_free_energy(const qbm_rbm_params* P, const float* x, int B, float* p
     if (!x || !pre_ws || (!neg_free_energy && !p_y_given_x)) return fail(QBM_ERR_ARG, "free_energy: null buffer");
     if (int rc = launch_hidden(P, x, QBM_F32, nullptr, B, pre_ws, nullptr, nullptr, 1, 0, 0, 0, (hipStream_t)stream)) return rc;
 #define QBM_L(CM)                                                                                               \
-    hipLaunchKernelGGL((k_free_energy<CM>), dim3(B), dim3(256), 0, (hipStream_t)stream, pre_ws, P->U,             \
-                       P->c, neg_free_energy, p_y_given_x, B, P->H, P->C)
+    hipLaunchKernelGGL((k_free_energy<CM>), dim3(B), dim3(64 * P->C), 0, (hipStream_t)stream, pre_ws, P->U,             \
+                       P->c, neg_free_energy, p_y_given_x, B, P->H, P->C, (const int*)nullptr, (float*)nullptr,   \
+                       (float*)nullptr, (float*)nullptr)
     QBM_DISPATCH_CM(P->C, QBM_L);
 #undef QBM_L
     QBM_CHECK_LAUNCH("k_free_energy");
@@ -914,9 +981,10 @@ int qbm_rbm_disc_class_grad(const qbm_rbm_params* P, const float* pre, const flo
     if (int rc = check_params(P)) return rc;
     if (B <= 0) return B == 0 ? QBM_OK : fail(QBM_ERR_ARG, "B < 0");
     if (!pre || !p_y || !labels || !gU) return fail(QBM_ERR_ARG, "disc_class_grad: null buffer");
-    const int n = P->C * ((P->H + 63) / 64);
-    hipLaunchKernelGGL(k_disc_class_grad, dim3(n), dim3(256), 0, (hipStream_t)stream, pre, P->U, p_y,
-                       labels, gU, gc, B, P->H, P->C);
+    const int n = P->C * ((P->H + 15) / 16);
+    hipLaunchKernelGGL(k_disc_class_grad, dim3(n), dim3(256), 0, (hipStream_t)stream, pre, P->U, p_y, labels,
+                       (float*)nullptr, gU, gc, (float*)nullptr, (float*)nullptr, StepScale{0.f, 0.f, 1.f, 0.f}, B, P->H,
+                       P->C, P->V);
     QBM_CHECK_LAUNCH("k_disc_class_grad");
     return QBM_OK;
 }
@@ -1023,23 +1091,36 @@ int qbm_rbm_disc_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const flo
     if (int rc = check_params(P)) return rc;
     if (B <= 0) return B == 0 ? QBM_OK : fail(QBM_ERR_ARG, "B < 0");
     if (!G || !G->gd || !G->gU || !G->gc) return fail(QBM_ERR_ARG, "disc_step: gd, gU, gc are required");
-    if (!x || !labels || !p_y || !ws || !ws->pre || !ws->pos || !ws->neg || !ws->onehot)
+    if (!x || !labels || !p_y || !ws || !ws->pre || !ws->pos || !ws->neg || !ws->onehot || !ws->cls_neg)
         return fail(QBM_ERR_ARG, "disc_step: null buffer");
     const bool fuse = apply_update && fuse_update;
     if (!fuse && !G->gW) return fail(QBM_ERR_ARG, "disc_step: gW is required unless the update is fused");
     if (apply_update && !(batch_size > 0.f)) return fail(QBM_ERR_ARG, "disc_step: batch_size must be positive");
-    if (int rc = qbm_rbm_free_energy(P, x, B, ws->pre, neg_free_energy, p_y, stream)) return rc;
-    if (int rc = qbm_rbm_disc_terms(P, ws->pre, p_y, labels, B, ws->pos, ws->neg, ws->onehot, stream)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    // 1. pre = d + x.W   2. -F, p(y|x), pos / neg / onehot per row   3. class part: usub = sum_i o p, gc (+ c, b update)
+    // 4. gW, gU, gd from the two "phases" (x, onehot, pos) and (x, -, neg); every remaining update fused
+    if (int rc = launch_hidden(P, x, QBM_F32, nullptr, B, ws->pre, nullptr, nullptr, 1, 0, 0, 0, st)) return rc;
+#define QBM_L(CM)                                                                                               \
+    hipLaunchKernelGGL((k_free_energy<CM>), dim3(B), dim3(64 * P->C), 0, st, ws->pre, P->U, P->c, neg_free_energy, p_y, \
+                       B, P->H, P->C, labels, ws->pos, ws->neg, ws->onehot)
+    QBM_DISPATCH_CM(P->C, QBM_L);
+#undef QBM_L
+    QBM_CHECK_LAUNCH("k_free_energy");
+    const StepScale sc{lr, factor, batch_size, sparse_constant};
+    hipLaunchKernelGGL(k_disc_class_grad, dim3(P->C * ((P->H + 15) / 16)), dim3(256), 0, st, ws->pre, P->U, p_y, labels,
+                       ws->cls_neg, (float*)nullptr, G->gc, fuse ? P->c : nullptr, fuse ? P->b : nullptr, sc, B, P->H,
+                       P->C, P->V);
+    QBM_CHECK_LAUNCH("k_disc_class_grad");
     qbm_rbm_grads g = *G;
     g.gb = nullptr;  // reference: visible_bias_grad = 0 (src/ClassificationRBM.py:138)
-    g.gc = nullptr;  // written by disc_class_grad below
+    g.gc = nullptr;  // written by k_disc_class_grad above
     if (fuse) g.gW = nullptr;
-    // W may be fused; U, c, d wait for disc_class_grad, so the U/B/C workgroups only write gradients here
+    qbm_rbm_params aux{nullptr, nullptr, P->d, P->U, nullptr, P->V, P->H, P->C};
     if (int rc = launch_grad(P->V, P->H, P->C, B, x, QBM_F32, ws->onehot, ws->pos, x, QBM_F32, nullptr, ws->neg, &g,
-                             fuse ? P->W : nullptr, nullptr, lr, factor, batch_size, sparse_constant, (hipStream_t)stream))
+                             fuse ? P->W : nullptr, fuse ? &aux : nullptr, lr, factor, batch_size, sparse_constant, st,
+                             ws->cls_neg))
         return rc;
-    if (int rc = qbm_rbm_disc_class_grad(P, ws->pre, p_y, labels, B, G->gU, G->gc, stream)) return rc;
-    if (apply_update) {
+    if (apply_update && !fuse) {
         g.gc = G->gc;
         return qbm_rbm_update(P, &g, lr, factor, batch_size, sparse_constant, stream);
     }

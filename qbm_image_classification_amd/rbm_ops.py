@@ -79,6 +79,7 @@ class HipRbmOps:
         if not torch.cuda.is_available():
             raise _lib.QbmHipError("no ROCm device visible: the HIP path cannot run (there is no CPU fallback)")
         self.device = torch.device(device)
+        self._disc_ws = None
 
     # ---- conditionals -------------------------------------------------------------------------
     def sample_hidden(self, P: ParamSet, v, y=None, seed=0, offset=0, row0=0, want_p=True, want_s=False):
@@ -173,11 +174,17 @@ class HipRbmOps:
     def disc_step(self, P: ParamSet, G: GradSet, x, labels, apply_update, fuse, lr, factor, batch_size, sparse):
         """One discriminative_training pass (src/ClassificationRBM.py:101-140). -> p(y|x) [B,C]"""
         x = _f32(x, self.device)
-        labels = torch.as_tensor(labels).to(device=self.device, dtype=torch.int32).contiguous()
+        if not (torch.is_tensor(labels) and labels.dtype == torch.int32 and labels.device == self.device
+                and labels.is_contiguous()):
+            labels = torch.as_tensor(labels).to(device=self.device, dtype=torch.int32).contiguous()
         B = x.shape[0]
-        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.device)
-        pre, pos, neg, oh, p = f(B, P.H), f(B, P.H), f(B, P.H), f(B, P.C), f(B, P.C)
-        ws = DiscWorkspace(ptr(pre), ptr(pos), ptr(neg), ptr(oh))
+        key = (B, P.H, P.C)
+        if self._disc_ws is None or self._disc_ws[0] != key:   # scratch reused from step to step (stream-ordered)
+            f = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.device)
+            bufs = (f(B, P.H), f(B, P.H), f(B, P.H), f(B, P.C), f(P.C, P.H))
+            self._disc_ws = (key, bufs, DiscWorkspace(*(ptr(t) for t in bufs)))
+        ws = self._disc_ws[2]
+        p = torch.empty(B, P.C, dtype=torch.float32, device=self.device)
         ps, gs = P.struct(), G.struct(with_gb=False)
         check(self.lib.qbm_rbm_disc_step(C.byref(ps), C.byref(gs), ptr(x), ptr(labels), B, ptr(p), None, C.byref(ws),
                                          int(apply_update), int(fuse), lr, factor, batch_size, sparse,

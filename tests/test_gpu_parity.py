@@ -142,7 +142,7 @@ def test_against_reference_golden(ops, name):
         assert np.max(np.abs(cpu(p) - g[f"pyx_{tag}"])) <= 2e-4
 
 
-@pytest.mark.parametrize("V,H,C,B", SHAPES)
+@pytest.mark.parametrize("V,H,C,B", SHAPES + [(100, 70, 15, 300), (64, 40, 5, 515)])  # + batch > one 256-row tile
 def test_discriminative_step_bitwise(ops, oracle, V, H, C, B):
     from qbm_image_classification_amd.rbm_ops import GradSet
 
