@@ -28,6 +28,7 @@
 // 16-byte zero page, so the MFMA loop needs no masks (fmaf(0, b, acc) == acc).
 #pragma once
 #include "qbm_device.cuh"
+#include <type_traits>
 
 // diagnostic builds (tools/microbench) define QBM_STAMP(i) to record s_memtime at phase boundaries;
 // in the product it expands to nothing
@@ -57,6 +58,15 @@ constexpr unsigned kOOB = 0x80000000u;  // operands are < 2 GiB (checked on the 
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+
+// byte offset of an LDS object inside the workgroup's LDS (the address operand of ds_* instructions)
+__device__ __forceinline__ uint32_t lds_off(const void* p)
+{
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
 }
 
 __device__ __forceinline__ void blds16(rsrc_t r, unsigned voff, void* lds_piece)
@@ -301,6 +311,7 @@ __device__ __forceinline__ StripOut<MT, NT> strip_mma(const AView& A, const BVie
                                               char* __restrict__ lds, int KP)
 {
     using TA = typename AView::elem;
+    const int qbm_diag = QBM_DIAG_MODE;   // 0 in the product: the diagnostic branches fold away
     constexpr bool A8 = sizeof(TA) == 1;
     constexpr bool A_K4 = AView::kK4, B_K4 = BView::kK4;
     constexpr int ASZ = (int)sizeof(TA);
@@ -325,105 +336,222 @@ __device__ __forceinline__ StripOut<MT, NT> strip_mma(const AView& A, const BVie
     QBM_STAMP(0);
 
     const int fragB = (B_K4 ? ((lane & 15) * 4 + (lane >> 4)) : lane) * 4;                  // byte offset in a piece
-    const int fragA = A8 ? (A_K4 ? (lane & 15) * 16 : (lane >> 4) * 16 + (lane & 15))       // u8: see header
+    const int fragA = A8 ? (A_K4 ? (lane & 15) * 16 + (lane >> 4) : (lane >> 4) * 16 + (lane & 15))  // u8: see header
                          : (A_K4 ? ((lane & 15) * 4 + (lane >> 4)) : lane) * 4;
-    const int shA = 8 * (lane >> 4);  // u8 k4: byte (lane>>4) of each dword
 
-    // fragments of one piece (4 k-steps): LDS -> registers, u8 widened to fp32
-    auto frag = [&](int pc, float (&fa)[MT][4], float (&fb)[NT][4]) {
+    // ---- MFMA loop over one "quad" (up to 4 pieces = 64 k).
+    // f32 MFMA runs at the vector rate and every VALU instruction of the wave displaces ~6-8 cycles of it (measured,
+    // tools/microbench/mfma_rate.hip), so the loop keeps VALU work to one widening per u8 value: fragment reads are
+    // asm with immediate piece offsets off one base register per tile, a u8 operand is read as single bytes
+    // (ds_read_u8 zero-extends: no shift), and the widenings of a piece go as one burst in front of its MFMAs.
+    // The reads are asm also so that the compiler's wait-count pass, which orders every LDS read it can see behind
+    // ALL pending LDS-DMA (vmcnt(0)), stays out of the loop: the transfers of the following quads land under these
+    // MFMAs.  The reads of piece p+1 are issued before the MFMAs of piece p behind counted lgkmcnt waits (LDS
+    // returns in order; a wait after the first <= 15 reads of p+1 covers everything older).
+    constexpr int kReadsA = A8 ? 4 : 2, kReadsB = 2;
+    constexpr int MT1 = (15 - kReadsB * NT) / kReadsA < MT ? (15 - kReadsB * NT) / kReadsA : MT;  // tiles in chunk 1
+    constexpr int kChunk1 = kReadsB * NT + kReadsA * MT1;   // <= 15 = the largest lgkmcnt
+    constexpr int kPieceA = A8 ? 256 : 1024;
+    struct Frag {
+        u32x2 a2[MT][2];     // fp32: k-steps (0,1) and (2,3)
+        uint32_t a1[MT][4];  // u8: one zero-extended byte per k-step
+        u32x2 b[NT][2];
+    };
+    auto readA = [&](auto PC, uint32_t ad, int i, Frag& f) {
+        constexpr int pc = decltype(PC)::value;
+#ifdef QBM_DIAG_NOREAD
+        for (int s = 0; s < 4; ++s) asm volatile("" : "=v"(f.a1[i][s]));
+        asm volatile("" : "=v"(f.a2[i][0])); asm volatile("" : "=v"(f.a2[i][1]));
+        return;
+#endif
+        if constexpr (A8) {
+            constexpr int st = A_K4 ? 4 : 64;   // k4 image: byte 4s+g of the row; lin image: 16-byte slot 4s+g
+            asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(f.a1[i][0]) : "v"(ad), "n"(pc * 256) : "memory");
+            asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(f.a1[i][1]) : "v"(ad), "n"(pc * 256 + st) : "memory");
+            asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(f.a1[i][2]) : "v"(ad), "n"(pc * 256 + 2 * st) : "memory");
+            asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(f.a1[i][3]) : "v"(ad), "n"(pc * 256 + 3 * st) : "memory");
+        } else {
+            asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(f.a2[i][0]) : "v"(ad), "n"(4 * pc), "n"(4 * pc + 1) : "memory");
+            asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(f.a2[i][1]) : "v"(ad), "n"(4 * pc + 2), "n"(4 * pc + 3) : "memory");
+        }
+    };
+    auto readB = [&](auto PC, uint32_t ad, int t, Frag& f) {
+        constexpr int pc = decltype(PC)::value;
+#ifdef QBM_DIAG_NOREAD
+        asm volatile("" : "=v"(f.b[t][0])); asm volatile("" : "=v"(f.b[t][1]));
+        return;
+#endif
+        asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(f.b[t][0]) : "v"(ad), "n"(4 * pc), "n"(4 * pc + 1) : "memory");
+        asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(f.b[t][1]) : "v"(ad), "n"(4 * pc + 2), "n"(4 * pc + 3) : "memory");
+    };
+    // the registers of `f` are valid after this (placed behind the wait that covers them): the widenings and MFMAs that
+    // consume them cannot be scheduled above it
+    auto tie = [&](Frag& f) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const char* ia = imgA + i * a_tile;
-            if constexpr (A8) {
-                if constexpr (A_K4) {
-                    const uint4 d = *reinterpret_cast<const uint4*>(ia + pc * 256 + fragA);
-                    fa[i][0] = (float)((d.x >> shA) & 255u); fa[i][1] = (float)((d.y >> shA) & 255u);
-                    fa[i][2] = (float)((d.z >> shA) & 255u); fa[i][3] = (float)((d.w >> shA) & 255u);
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) fa[i][s] = (float)*reinterpret_cast<const uint8_t*>(ia + pc * 256 + s * 64 + fragA);
-                }
-            } else {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) fa[i][s] = *reinterpret_cast<const float*>(ia + pc * 1024 + s * 256 + fragA);
-            }
+        for (int t = 0; t < NT; ++t) {
+            asm volatile("" : "+v"(f.b[t][0]));
+            asm volatile("" : "+v"(f.b[t][1]));
         }
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int i = 0; i < MT; ++i) {
+            if constexpr (A8) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) fb[t][s] = *reinterpret_cast<const float*>(imgB + t * b_tile + pc * 1024 + s * 256 + fragB);
+                for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(f.a1[i][s]));
+            } else {
+                asm volatile("" : "+v"(f.a2[i][0]));
+                asm volatile("" : "+v"(f.a2[i][1]));
+            }
+        }
     };
-    auto mma = [&](const float (&fa)[MT][4], const float (&fb)[NT][4]) {
+    auto mma = [&](const Frag& f) {
+        float av[MT][4];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#ifdef QBM_DIAG_NOCVT
+                if constexpr (A8) av[i][s] = __uint_as_float(f.a1[i][s]);
+#else
+                if constexpr (A8) av[i][s] = (float)f.a1[i][s];
+#endif
+                else av[i][s] = __uint_as_float(f.a2[i][s >> 1][s & 1]);
+            }
+        if constexpr (A8) {   // the widenings as one burst in front of the MFMAs (no wait states between them)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(av[i][0]), "+v"(av[i][1]), "+v"(av[i][2]), "+v"(av[i][3]));
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][s], fb[t][s], acc[i][t], 0, 0, 0);
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][s], __uint_as_float(f.b[t][s >> 1][s & 1]), acc[i][t], 0, 0, 0);
     };
-    // MFMA over pieces [p0, p1): the fragments of piece pc+1 are read while the MFMAs of piece pc issue.
-    // No asm and no barrier inside, so that the compiler software-pipelines the ds_reads under the MFMAs.
-    auto run = [&](int p0, int p1) {
-        float a0[MT][4], b0[NT][4], a1[MT][4], b1[NT][4];
-        if (p0 < p1) frag(p0, a0, b0);
+    // the NP pieces of quad `qd`, straight-line (no branch inside: a merge point would cost register copies, and
+    // copies are VALU work the MFMAs pay for)
+    auto run_quad_n = [&](auto NPC, int qd) {
+        constexpr int NP = decltype(NPC)::value;
+        using std::integral_constant;
+        uint32_t adA[MT], adB[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) adA[i] = lds_off(imgA) + (uint32_t)(fragA + i * a_tile + qd * 4 * kPieceA);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) adB[t] = lds_off(imgB) + (uint32_t)(fragB + t * b_tile + qd * 4096);
+        auto reads1 = [&](auto PC, Frag& f) {   // chunk 1: at most 15 reads
+#pragma unroll
+            for (int t = 0; t < NT; ++t) readB(PC, adB[t], t, f);
+#pragma unroll
+            for (int i = 0; i < MT1; ++i) readA(PC, adA[i], i, f);
+        };
+        auto reads2 = [&](auto PC, Frag& f) {
+#pragma unroll
+            for (int i = MT1; i < MT; ++i) readA(PC, adA[i], i, f);
+        };
+        // one pipeline stage: issue the reads of piece NXT into `fn` (if the quad has it), then the MFMAs of the piece in `fc`
+        auto stage = [&](auto NXT, Frag& fn, Frag& fc) {
+            constexpr int nxt = decltype(NXT)::value;
+            if constexpr (nxt < NP) {
+                reads1(NXT, fn);
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(kChunk1) : "memory");   // everything older than chunk 1 has landed
+                tie(fc);
+                reads2(NXT, fn);
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                tie(fc);
+            }
+            mma(fc);
+        };
+        Frag f0, f1;
+        reads1(integral_constant<int, 0>{}, f0);
+        reads2(integral_constant<int, 0>{}, f0);
+        stage(integral_constant<int, 1>{}, f1, f0);
+        if constexpr (NP > 1) stage(integral_constant<int, 2>{}, f0, f1);
+        if constexpr (NP > 2) stage(integral_constant<int, 3>{}, f1, f0);
+        if constexpr (NP > 3) stage(integral_constant<int, 4>{}, f0, f1);
+    };
+    auto run_quad = [&](int qd, int np) {   // np = pieces in the quad, 1..4 (wave-uniform)
+        using std::integral_constant;
+        if (np >= 4) run_quad_n(integral_constant<int, 4>{}, qd);
+        else if (np == 3) run_quad_n(integral_constant<int, 3>{}, qd);
+        else if (np == 2) run_quad_n(integral_constant<int, 2>{}, qd);
+        else if (np == 1) run_quad_n(integral_constant<int, 1>{}, qd);
+    };
+    auto run = [&](int p0, int p1) {   // whole quads from p0 (a multiple of 4)
         int pc = p0;
-        for (; pc + 1 < p1; pc += 2) {
-            frag(pc + 1, a1, b1);
-            mma(a0, b0);
-            if (pc + 2 < p1) frag(pc + 2, a0, b0);
-            mma(a1, b1);
-        }
-        if (pc < p1) mma(a0, b0);
+        for (; pc + 4 <= p1; pc += 4) run_quad_n(std::integral_constant<int, 4>{}, pc >> 2);
+        if (pc < p1) run_quad(pc >> 2, p1 - pc);
     };
 
     for (int kb = kq0; kb < kq0 + Kq; kb += KP) {
         const int klen = max(0, min(kend - kb, KP));
         const int pieces = (klen + 15) >> 4;   // 16 k per piece (klen is a multiple of 16 on the FAST path)
         if constexpr (FAST_A && FAST_B) {
-            // ---- LDS-DMA: every instruction of this wave's K range is issued before anything is waited for.
-            // Issue order: per piece [A tiles (u8: once per 4 pieces), B tiles].
+            // ---- LDS-DMA, two quads ahead of the MFMAs: the transfers of quads q+1, q+2 are in flight while quad q
+            // is contracted.  The compiler does not order a ds_read behind a pending LDS-DMA, so each quad sits
+            // behind an explicit counted vmcnt wait.
             const rsrc_t ra = A.rsrc(), rb = Bv.rsrc();
             DmaLane la[MT], lb[NT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) la[i] = A.lane0(m0 + 16 * i, kb, lane);
 #pragma unroll
             for (int t = 0; t < NT; ++t) lb[t] = Bv.lane0(n0 + 16 * t, kb, lane);
-            const int half = (pieces + 1) >> 1;
-            int issued_half = 0, issued = 0;
-            for (int pc = 0; pc < (QBM_DIAG_MODE == 4 ? 0 : pieces); ++pc) {
-                if (!A8 || (pc & 3) == 0) {
+            const int quads = (pieces + 3) >> 2;
+            auto quad_pieces = [&](int qd) { return min(4, pieces - 4 * qd); };
+            auto quad_dmas = [&](int qd) { return qd < quads ? (A8 ? MT : MT * quad_pieces(qd)) + NT * quad_pieces(qd) : 0; };
+            auto issue_quad = [&](int qd) {
+                const int np = quad_pieces(qd);
+                if constexpr (A8) {
 #pragma unroll
                     for (int i = 0; i < MT; ++i) {
-                        // u8: one instruction covers 4 pieces; lanes past the end of the K quarter read zeros
-                        const unsigned off = (!A8 || la[i].k < kend) ? la[i].voff : kOOB;
-                        blds16(ra, off, imgA + i * a_tile + (A8 ? (pc >> 2) : pc) * 1024);
+                        // u8: one instruction covers the 4 pieces; lanes past the end of the K quarter read zeros
+                        blds16(ra, la[i].k < kend ? la[i].voff : kOOB, imgA + i * a_tile + qd * 1024);
                         la[i].voff += la[i].step;
                         la[i].k += la[i].kstep;
                     }
-                    issued += MT;
                 }
+                for (int pc = 4 * qd; pc < 4 * qd + np; ++pc) {
+                    if constexpr (!A8) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    blds16(rb, lb[t].voff, imgB + t * b_tile + pc * 1024);
-                    lb[t].voff += lb[t].step;
+                        for (int i = 0; i < MT; ++i) {
+                            blds16(ra, la[i].voff, imgA + i * a_tile + pc * 1024);
+                            la[i].voff += la[i].step;
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        blds16(rb, lb[t].voff, imgB + t * b_tile + pc * 1024);
+                        lb[t].voff += lb[t].step;
+                    }
                 }
-                issued += NT;
-                if (pc == half - 1) issued_half = issued;
+            };
+            if (qbm_diag != 4) {
+                if (quads > 0) issue_quad(0);
+                if (quads > 1) issue_quad(1);
             }
             QBM_STAMP(1);
-            // The compiler does not order a ds_read behind a pending LDS-DMA: the two halves of the MFMA
-            // loop sit behind explicit vmcnt waits (counted for the first half, so that the second half of
-            // the transfers lands under the first half of the MFMAs).
-            if (QBM_DIAG_MODE == 4) {
-                QBM_STAMP(2);
-                run(0, pieces);
-            } else {
-                if (QBM_DIAG_MODE == 1) vm_wait(0); else vm_wait(issued - issued_half);
-                QBM_STAMP(2);
-                if (QBM_DIAG_MODE != 3) run(0, half);
-                vm_wait(0);
-                if (QBM_DIAG_MODE != 3) run(half, pieces);
+            // Full quads run in one loop body (one code path: the accumulators stay in place); the wait before quad qd
+            // leaves the transfers of quads qd+1, qd+2 in flight, counted with constants (a full quad is kFull DMA
+            // instructions; the tail quad is counted as none, which only waits a little longer than necessary).
+            constexpr int kFull = (A8 ? MT : 4 * MT) + 4 * NT;
+            static_assert(2 * kFull <= 63, "two quads of LDS-DMA must fit the vmcnt range");
+            const int full = pieces >> 2;
+            int qd = 0;
+            for (; qd < full; ++qd) {
+                if (qbm_diag != 4) {
+                    if (qd + 2 < quads) issue_quad(qd + 2);
+                    if (qbm_diag == 1) vm_wait(0);
+                    else if (qd + 2 < full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kFull) : "memory");
+                    else if (qd + 1 < full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kFull) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                if (qd == 0) QBM_STAMP(2);
+                if (qbm_diag != 3) run_quad_n(std::integral_constant<int, 4>{}, qd);
+            }
+            if (qd < quads) {   // tail quad: 1..3 pieces, nothing is in flight behind it
+                if (qbm_diag != 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (qd == 0) QBM_STAMP(2);
+                if (qbm_diag != 3) run_quad(qd, pieces - 4 * qd);
             }
         } else {
             // ---- at least one operand goes through registers (unaligned / ragged / synthesised)

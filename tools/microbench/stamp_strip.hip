@@ -87,10 +87,14 @@ void run(const char* name, int diag)
 
 int main()
 {
-    run<uint8_t>("u8 A, product path (half-way counted vmcnt)", 0);
-    run<uint8_t>("u8 A, one vmcnt(0) before the MFMA loop", 1);
+#if defined(QBM_DIAG_NOCVT) || defined(QBM_DIAG_NOREAD)
+    run<uint8_t>("u8 A, MFMA loop alone, diagnostic build (see -D flags)", 4);
+#else
+    run<uint8_t>("u8 A, product path (DMA two quads ahead)", 0);
+    run<uint8_t>("u8 A, every DMA landed before the MFMA loop", 1);
     run<uint8_t>("u8 A, no MFMA loop", 3);
     run<uint8_t>("u8 A, MFMA loop alone (no staging, no waits)", 4);
     run<float>("fp32 A, product path", 0);
+#endif
     return 0;
 }
