@@ -177,21 +177,26 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
 // ---------------------------------------------------------------------------------------------
 // A-3  sample_class  (src/ClassificationRBM.py:54-60): exp(h.U^T + c), L1-normalised (eps 1e-12);
 // categorical draw: one uniform per row, first class whose running sum exceeds u.
-// One wavefront per row; the sum over j is the wave tree [T].  All loads are unconditional.
+// One workgroup per row: wave w takes the classes c = w, w+4, ... (per class the sum over j is the wave tree [T],
+// exactly as one wave would do it), the energies meet in LDS (`e_s`, QBM_MAX_CLASSES floats) and thread 0 normalises
+// and draws.  All loads are unconditional.
 // ---------------------------------------------------------------------------------------------
 template <class TH, int CM>
 __device__ __forceinline__ void class_row(const void* __restrict__ h, const float* __restrict__ U,
                                           const float* __restrict__ cb, float* __restrict__ p_out,
                                           float* __restrict__ y_out, int i, int H, int C, uint64_t seed,
-                                          uint64_t offset, uint32_t row0, int lane)
+                                          uint64_t offset, uint32_t row0, float* __restrict__ e_s)
 {
-    float e[CM], cbv[CM];
+    constexpr int CW = (CM + 3) / 4;   // classes per wave
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float e[CW], cbv[CW];
 #pragma unroll
-    for (int c = 0; c < CM; ++c) { e[c] = 0.f; cbv[c] = cb[min(c, C - 1)]; }
+    for (int t = 0; t < CW; ++t) { e[t] = 0.f; cbv[t] = cb[min(w + 4 * t, C - 1)]; }
     // per class the lane chains j = lane, lane+64, ... ascending ([T]).  256 columns per trip: all
-    // 4 + 4*CM loads of a trip are unconditional (index clamped, h masked to 0: fmaf(0, u, e) == e)
+    // 4 + 4*CW loads of a trip are unconditional (index clamped, h masked to 0: fmaf(0, u, e) == e)
     for (int jb = 0; jb < H; jb += 4 * kWave) {
-        float hv[4], uv[4][CM];
+        float hv[4], uv[4][CW];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int j = jb + t * kWave + lane;
@@ -199,20 +204,27 @@ __device__ __forceinline__ void class_row(const void* __restrict__ h, const floa
             const float x = ld_state<TH>(h, (long)i * H + jj);
             hv[t] = (j < H) ? x : 0.f;
 #pragma unroll
-            for (int c = 0; c < CM; ++c) uv[t][c] = U[(long)min(c, C - 1) * H + jj];
+            for (int c = 0; c < CW; ++c) uv[t][c] = U[(long)min(w + 4 * c, C - 1) * H + jj];
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int c = 0; c < CM; ++c) e[c] = __builtin_fmaf(hv[t], uv[t][c], e[c]);
+            for (int c = 0; c < CW; ++c) e[c] = __builtin_fmaf(hv[t], uv[t][c], e[c]);
     }
 #pragma unroll
-    for (int c = 0; c < CM; ++c) e[c] = det_expf(wave_butterfly_sum(e[c]) + cbv[c]);
-    if (lane != 0) return;
+    for (int t = 0; t < CW; ++t) {
+        const float v = det_expf(wave_butterfly_sum(e[t]) + cbv[t]);
+        if (lane == 0 && w + 4 * t < C) e_s[w + 4 * t] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    float ev[CM];
+#pragma unroll
+    for (int c = 0; c < CM; ++c) ev[c] = e_s[min(c, C - 1)];
     float denom = 0.f;
 #pragma unroll
     for (int c = 0; c < CM; ++c)
-        if (c < C) denom = denom + __builtin_fabsf(e[c]);
+        if (c < C) denom = denom + __builtin_fabsf(ev[c]);
     if (!(denom > 1e-12f)) denom = 1e-12f;
     const float u = uniform4(seed, offset, row0 + (uint32_t)i, 0u)[0];
     float cum = 0.f;
@@ -221,7 +233,7 @@ __device__ __forceinline__ void class_row(const void* __restrict__ h, const floa
 #pragma unroll
     for (int c = 0; c < CM; ++c) {
         if (c < C) {
-            const float p = e[c] / denom;
+            const float p = ev[c] / denom;
             if (p_out) p_out[(long)i * C + c] = p;
             cum = cum + p;
             if (!done && u < cum) { pick = c; done = true; }
@@ -237,15 +249,15 @@ __global__ __launch_bounds__(256) void k_class(const void* __restrict__ h, const
                                                float* __restrict__ y_out, int B, int H, int C, uint64_t seed,
                                                uint64_t offset, uint32_t row0)
 {
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i < B) class_row<TH, CM>(h, U, cb, p_out, y_out, i, H, C, seed, offset, row0, threadIdx.x & 63);
+    __shared__ float e_s[QBM_MAX_CLASSES + 1];
+    class_row<TH, CM>(h, U, cb, p_out, y_out, (int)blockIdx.x, H, C, seed, offset, row0, e_s);
 }
 
 // ---------------------------------------------------------------------------------------------
 // A-2  sample_visible  (src/ClassificationRBM.py:49-52):  p = sigma(h.W^T + b);  v = (p > u)
 // W is read as stored ([V,H], H contiguous): it is the K-contiguous B operand.
 // The launch can carry the class conditional of the same hidden state (A-3) as extra workgroups
-// placed first in the grid (8 rows each): both read h only, so one launch serves both and the tiny
+// placed first in the grid (one row each): both read h only, so one launch serves both and the tiny
 // class product hides behind the strips.
 // ---------------------------------------------------------------------------------------------
 struct VisibleArgs {
@@ -270,11 +282,9 @@ template <class TA, bool FAST, int CM>
 __global__ __launch_bounds__(256) void k_visible(VisibleArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    if ((int)blockIdx.x < a.n_aux) {  // aux workgroup (dealt first): class conditional, 8 rows, 2 per wave
-        const int base = (int)blockIdx.x * 8 + (threadIdx.x >> 6) * 2;
-        for (int r = 0; r < 2; ++r)
-            if (base + r < a.B)
-                class_row<TA, CM>(a.h, a.U, a.cb, a.py, a.ys, base + r, a.H, a.C, a.seed, a.offset_y, a.row0, threadIdx.x & 63);
+    if ((int)blockIdx.x < a.n_aux) {  // aux workgroup (dealt first): class conditional of one row
+        class_row<TA, CM>(a.h, a.U, a.cb, a.py, a.ys, (int)blockIdx.x, a.H, a.C, a.seed, a.offset_y, a.row0,
+                          reinterpret_cast<float*>(lds));
         return;
     }
     constexpr int MT = V_MT, NT = V_NT;
@@ -799,7 +809,7 @@ int launch_visible_t(const qbm_rbm_params* P, const void* h, int B, float* p_v, 
     VisibleArgs a{h, P->W, P->b, p_v, v_s, v_s8, B, P->V, P->H, panel_for<MT, NT, ASZ>(P->H), seed, offset_v, row0,
                   (P->V % 4 == 0) && (!p_v || aligned16(p_v)) && (!v_s || aligned16(v_s)) && (!v_s8 || aligned16(v_s8)) &&
                       aligned16(P->b),
-                  P->U, P->c, p_y, y1hot, P->C, offset_y, with_class ? (B + 7) / 8 : 0};
+                  P->U, P->c, p_y, y1hot, P->C, offset_y, with_class ? B : 0};
     const bool fast = (P->H % 16 == 0) && aligned16(h) && aligned16(P->W) && small2g((long)B * P->H, ASZ) &&
                       small2g((long)P->V * P->H, 4);
     const int grid = nM * nN + a.n_aux;
@@ -936,7 +946,7 @@ int qbm_rbm_sample_class(const qbm_rbm_params* P, const float* h, int B, float* 
     if (B == 0) return QBM_OK;
     if (!h || (!p_y && !y1hot)) return fail(QBM_ERR_ARG, "sample_class: null input/output");
 #define QBM_L(CM)                                                                                                  \
-    hipLaunchKernelGGL((k_class<float, CM>), dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, h, P->U, P->c, p_y, \
+    hipLaunchKernelGGL((k_class<float, CM>), dim3(B), dim3(256), 0, (hipStream_t)stream, h, P->U, P->c, p_y, \
                        y1hot, B, P->H, P->C, seed, offset, row0)
     QBM_DISPATCH_CM(P->C, QBM_L);
 #undef QBM_L

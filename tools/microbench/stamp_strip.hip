@@ -16,8 +16,7 @@ __device__ int g_diag;
 #include "strip_mma.cuh"
 using namespace qbm;
 
-constexpr int MT = 2, NT = 1;
-template <class TA>
+template <class TA, int MT, int NT, bool BK4>
 __global__ __launch_bounds__(256) void k_h(const TA* v, const float* y, const float* W, const float* d, const float* U, float* p, float* s, int B, int V, int H, int C, int KP)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -27,7 +26,9 @@ __global__ __launch_bounds__(256) void k_h(const TA* v, const float* y, const fl
     const int m0 = ms * 16 * MT, n0 = ns * 16 * NT;
     using AV = typename std::conditional<sizeof(TA) == 1, ViewKContigU8, ViewKContig>::type;
     const AV A{v, V, B};
-    const ViewCContig Bv{W, H, H, V};
+    using BV = typename std::conditional<BK4, ViewKContig, ViewCContig>::type;
+    BV Bv;
+    if constexpr (BK4) Bv = BV{W, V, H}; else Bv = BV{W, H, H, V};   // k4: W^T as [H rows][V contiguous k]
     const auto o = strip_mma<MT, NT, true, true>(A, Bv, m0, n0, V, lds, KP);
     QBM_STAMP(5);
     if (o.valid(0)) {
@@ -48,11 +49,11 @@ __global__ __launch_bounds__(256) void k_h(const TA* v, const float* y, const fl
     QBM_STAMP(6);
 }
 
-template <class TA>
-void run(const char* name, int diag)
+template <class TA, int MT = 2, int NT = 1, bool BK4 = false>
+void run(const char* name, int diag, int B = 256, int V = 784, int H = 512)
 {
     hipMemcpyToSymbol(HIP_SYMBOL(g_diag), &diag, sizeof(int));
-    const int B = 256, V = 784, H = 512, C = 10;
+    const int C = 10;
     TA* v; float *y, *W, *d, *U, *p, *s;
     hipMalloc(&v, sizeof(TA) * B * V); hipMalloc(&y, sizeof(float) * B * C); hipMalloc(&W, sizeof(float) * V * H);
     hipMalloc(&d, sizeof(float) * H); hipMalloc(&U, sizeof(float) * C * H); hipMalloc(&p, sizeof(float) * B * H); hipMalloc(&s, sizeof(float) * B * H);
@@ -61,12 +62,12 @@ void run(const char* name, int diag)
     const int Kq = quarter_len(V); int KP = (Kq + 63) / 64 * 64;
     if (KP > strip_max_panel<MT, NT, sizeof(TA)>()) KP = strip_max_panel<MT, NT, sizeof(TA)>();
     const size_t lds = strip_lds_bytes<MT, NT, sizeof(TA)>(KP);
-    hipFuncSetAttribute((const void*)k_h<TA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int grid = ((B + 31) / 32) * (H / 16);
+    hipFuncSetAttribute((const void*)k_h<TA, MT, NT, BK4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int grid = ((B + 16 * MT - 1) / (16 * MT)) * (H / (16 * NT));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int it = 0; it < 5; ++it) hipLaunchKernelGGL((k_h<TA>), dim3(grid), dim3(256), lds, 0, v, y, W, d, U, p, s, B, V, H, C, KP);
+    for (int it = 0; it < 5; ++it) hipLaunchKernelGGL((k_h<TA, MT, NT, BK4>), dim3(grid), dim3(256), lds, 0, v, y, W, d, U, p, s, B, V, H, C, KP);
     hipEventRecord(e0);
-    for (int it = 0; it < 200; ++it) hipLaunchKernelGGL((k_h<TA>), dim3(grid), dim3(256), lds, 0, v, y, W, d, U, p, s, B, V, H, C, KP);
+    for (int it = 0; it < 200; ++it) hipLaunchKernelGGL((k_h<TA, MT, NT, BK4>), dim3(grid), dim3(256), lds, 0, v, y, W, d, U, p, s, B, V, H, C, KP);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("== %s: grid %d, LDS %zu B/block, %.2f us/launch back-to-back (stamped build)\n", name, grid, lds, ms / 200 * 1000);
@@ -95,6 +96,10 @@ int main()
     run<uint8_t>("u8 A, no MFMA loop", 3);
     run<uint8_t>("u8 A, MFMA loop alone (no staging, no waits)", 4);
     run<float>("fp32 A, product path", 0);
+    // visible-like: K = 512 (hidden units), N = 784 -> 800 (visible units, padded here to whole strips), B operand K-contiguous
+    run<uint8_t, 4, 1, true>("visible-like 64x16 strips, K=512, product path", 0, 256, 512, 784);
+    run<uint8_t, 4, 1, true>("visible-like 64x16 strips, K=512, no MFMA loop", 3, 256, 512, 784);
+    run<uint8_t, 4, 1, true>("visible-like 64x16 strips, K=512, MFMA loop alone", 4, 256, 512, 784);
 #endif
     return 0;
 }
