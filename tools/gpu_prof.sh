@@ -4,7 +4,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/prof_cur
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_cur -- python3 $GRAFT_REPO_ROOT/bench.py --steps 500 --warmup 50 --graph 0 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err || (tail -20 $OUT/prof.err; exit 1)
-f=$(find $OUT/prof_cur -name "*kernel_stats.csv" | head -1)
+f=$(ls -t $(find $OUT/prof_cur -name "*kernel_stats.csv") | head -1)
 python3 - "$f" <<'PY'
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
