@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QBM_ABI_VERSION 3
+#define QBM_ABI_VERSION 4
 #define QBM_MAX_CLASSES 15 /* class rows + the bias row share one 16-row gradient tile */
 #define QBM_MAX_QUBO_VARS 1024
 
@@ -37,6 +37,7 @@ extern "C" {
  * binary states and 4x less L2 -> LDS staging traffic, the resource that bounds these kernels) */
 #define QBM_F32 0
 #define QBM_U8 1
+#define QBM_BITS 2 /* bit-packed {0,1} rows, MSB first (numpy.packbits), ceil(V/8) bytes per row: dataset storage only */
 
 #define QBM_OK 0
 #define QBM_ERR_ARG (-1) /* bad dimension / null pointer */
@@ -191,6 +192,27 @@ QBM_API int qbm_rbm_disc_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, c
                               const int32_t* labels, int B, float* p_y, float* neg_free_energy,
                               const qbm_rbm_disc_workspace* ws, int apply_update, int fuse_update, float lr,
                               float factor, float batch_size, float sparse_constant, void* stream);
+
+/* ---- device-resident dataset pipeline ----------------------------------
+ * The outputs of src/data_loader.py (get_mnist :23-73, get_medmnist :115-169, preprocess_images :240-277) are moved
+ * to the device once; torch.utils.data.DataLoader(shuffle=True) of rbm_main.py:70-74 is replaced by an on-device
+ * permutation + one gather launch per minibatch. */
+
+/* {0,1} uint8 states from greyscale: out = x > threshold */
+QBM_API int qbm_data_binarise(const float* x, long n, float threshold, uint8_t* out, void* stream);
+
+/* [N,V] {0,1} uint8 -> [N, ceil(V/8)] bytes, MSB first (numpy.packbits(axis=1)): 98 B per 28x28 image */
+QBM_API int qbm_data_pack_bits(const uint8_t* x, int N, int V, uint8_t* bits, void* stream);
+
+/* sort keys of the epoch permutation: keys[i] = Philox4x32-10(key = seed, counter = (i>>2, 0, epoch))[i&3] >> 1;
+ * the permutation is their stable ascending argsort */
+QBM_API int qbm_data_shuffle_keys(uint64_t seed, uint64_t epoch, int N, int32_t* keys, void* stream);
+
+/* minibatch gather: dst[r,:] = set[idx[r],:], src_kind QBM_F32 / QBM_U8 / QBM_BITS -> dst_kind QBM_F32 / QBM_U8
+ * (fp32 -> uint8 truncates: binary data only); labels (int32 [N], optional) -> labels_out[B] and/or one-hot
+ * y1hot[B,C].  idx values must lie in [0, N). */
+QBM_API int qbm_data_gather(const void* src, int src_kind, const int32_t* idx, int B, int V, void* dst, int dst_kind,
+                            const int32_t* labels, int32_t* labels_out, float* y1hot, int C, void* stream);
 
 /* ---- Disc_QBM: QUBO sampler ------------------------------------------------------------------ */
 

@@ -77,6 +77,34 @@ def philox_raw(key, ctr) -> np.ndarray:
     return out
 
 
+def data_shuffle_keys(seed: int, epoch: int, n: int) -> np.ndarray:
+    out = np.empty(n, np.int32)
+    f = lib().orc_shuffle_keys
+    f.argtypes = [C.c_uint64, C.c_uint64, C.c_int, np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")]
+    f.restype = None
+    f(seed, epoch, n, out)
+    return out
+
+
+def data_shuffle_perm(seed: int, epoch: int, n: int) -> np.ndarray:
+    """Epoch permutation of the device-resident dataset: stable ascending argsort of the Philox keys."""
+    return np.argsort(data_shuffle_keys(seed, epoch, n), kind="stable").astype(np.int64)
+
+
+def data_gather(x, idx, labels=None, num_classes=0, bits_visible=None, out_dtype=np.float32):
+    """Minibatch gather (+ unpacking of MSB-first bit-packed rows when bits_visible is given) with labels / one-hot."""
+    x = np.asarray(x)
+    rows = x[np.asarray(idx)]
+    if bits_visible is not None:
+        rows = np.unpackbits(rows.astype(np.uint8), axis=1)[:, :bits_visible]
+    rows = rows.astype(out_dtype)
+    if labels is None:
+        return rows
+    lab = np.asarray(labels)[np.asarray(idx)].astype(np.int32)
+    onehot = (lab[:, None] == np.arange(num_classes)[None, :]).astype(np.float32)
+    return rows, lab, onehot
+
+
 def math(which: str, x) -> np.ndarray:
     x = _f32(x)
     y = np.empty_like(x)

@@ -213,11 +213,14 @@ class ClassificationRBM:
         nll_list = []
         best_validation_model = None
         for epoch in range(epochs):
-            epoch_error = 0.0
-            epoch_nll = 0.0
+            # the running sums live on the device as float64 scalars: the same IEEE double additions, in the same
+            # order, as the reference's `epoch_error += batch_error.item()` -- without a host sync per step
+            epoch_error_t = torch.zeros((), dtype=torch.float64, device=self.device)
+            epoch_nll_t = torch.zeros((), dtype=torch.float64, device=self.device)
             for batch, labels in train_loader:
                 batch = batch.view(len(batch), self.num_visible)  # flatten input data (:173)
-                batch = batch.to(self.device, torch.float32)
+                # uint8 {0,1} minibatches (device_data.DeviceDataset) stay bytes: the Gibbs kernels read them as such
+                batch = batch.to(self.device) if batch.dtype == torch.uint8 else batch.to(self.device, torch.float32)
                 labels = labels.to(self.device)
                 if method == 'discriminative':
                     batch_error, _, class_probs = self.discriminative_training(batch, labels, discriminative_factor)
@@ -232,12 +235,13 @@ class ClassificationRBM:
                 else:
                     raise NotImplementedError(method)
 
-                epoch_error += batch_error.item()
+                epoch_error_t += batch_error.detach().double()
                 # NLL of the batch (:188-191)
                 log_probs = torch.log(class_probs + 1e-8)
                 nll = -log_probs[torch.arange(batch.size(0), device=self.device), labels.long()]
-                epoch_nll += nll.mean().item()
+                epoch_nll_t += nll.mean().double()
 
+            epoch_error, epoch_nll = epoch_error_t.item(), epoch_nll_t.item()
             loss_list.append(epoch_error / len(train_loader))
             nll_list.append(epoch_nll / len(train_loader))
 

@@ -41,6 +41,7 @@ parser.add_argument('--binarise', action='store_true', help='threshold the image
 parser.add_argument('--persistent', action='store_true', help='PCD instead of CD-k for generative/hybrid training')
 parser.add_argument('--bars-and-stripes', action='store_true', help='4x4 Bars-and-Stripes instead of BreastMNIST (16 visible units)')
 parser.add_argument('--out-dir', type=str, default='Breast_beta_hyper_RBM')
+parser.add_argument('--host-loader', action='store_true', help="torch DataLoader(shuffle=True) as in the reference instead of the device-resident dataset")
 
 
 def find_breastmnist(root):
@@ -83,7 +84,13 @@ def main(args):
         test_y_t = torch.from_numpy(np.array(test_y)).to(device).long()
         training_dataset = torch.utils.data.TensorDataset(torch.from_numpy(train_X).to(device), train_y_t)
         test_dataset = torch.utils.data.TensorDataset(torch.from_numpy(test_X).to(device), test_y_t)
-        train_loader = torch.utils.data.DataLoader(training_dataset, batch_size=args.batch_size, shuffle=True)
+        if args.host_loader:   # the reference's loader: host-side shuffling and slicing every step
+            train_loader = torch.utils.data.DataLoader(training_dataset, batch_size=args.batch_size, shuffle=True)
+        else:                  # default: the set lives on the GPU, permutation + gather happen there
+            from qbm_image_classification_amd.device_data import DeviceDataset
+
+            train_loader = DeviceDataset(train_X, np.array(train_y), args.batch_size, num_classes=2,
+                                         storage="bits" if args.binarise else "f32", seed=seed, device=str(rbm.device))
         test_loader = torch.utils.data.DataLoader(test_dataset, batch_size=len(training_dataset), shuffle=False)
 
         loss_list, best_model, nll_list = rbm.train_rbm(train_loader=train_loader, test_loader=test_loader,

@@ -111,3 +111,38 @@ class OracleRbmOps:
         if fuse:
             self.update(P, G, lr, factor, batch_size, sparse)
         return tuple(torch.from_numpy(a) for a in (ph0, vk.astype(np.uint8), vk.astype(np.uint8), yk, phk))
+
+
+class OracleDataOps:
+    """CPU double of device_data.HipDataOps (binarise / pack_bits / permutation / gather through the oracle), so that
+    DeviceDataset's host logic -- batch walk, rank sharding, epoch counter -- is covered without a GPU."""
+
+    def __init__(self):
+        import torch
+
+        self.device = torch.device("cpu")
+
+    def binarise(self, x, threshold=0.5):
+        import torch
+
+        return (x.to(torch.float32) > threshold).to(torch.uint8)
+
+    def pack_bits(self, x_u8):
+        import torch
+
+        return torch.from_numpy(np.packbits(x_u8.numpy().astype(np.uint8), axis=1))
+
+    def permutation(self, seed, epoch, n):
+        import torch
+
+        return torch.from_numpy(orc.data_shuffle_perm(seed, epoch, n).astype(np.int32))
+
+    def gather(self, src, src_kind, idx, num_visible, dst_kind=0, labels=None, num_classes=0, want_onehot=False):
+        import torch
+
+        out = orc.data_gather(src.numpy(), idx.numpy(), None if labels is None else labels.numpy(), num_classes,
+                              num_visible if src_kind == 2 else None, np.float32 if dst_kind == 0 else np.uint8)
+        if labels is None:
+            return torch.from_numpy(out), None, None
+        rows, lab, one = out
+        return torch.from_numpy(rows), torch.from_numpy(lab), torch.from_numpy(one) if want_onehot else None

@@ -1,0 +1,151 @@
+"""Device-resident dataset pipeline.
+CPU part: the oracle restatement (Philox shuffle keys, permutation, gather / bit unpacking) and DeviceDataset's host
+logic through the oracle-backed double.  GPU part (-m gpu): the HIP entry points against the oracle, bit for bit."""
+import numpy as np
+import pytest
+
+from helpers import golden
+
+torch = pytest.importorskip("torch")
+
+
+def _set(n=37, v=784, classes=3, seed=0):
+    rs = np.random.RandomState(seed)
+    x = rs.random_sample((n, v)).astype(np.float32)
+    y = rs.randint(0, classes, n)
+    return x, y
+
+
+def test_oracle_shuffle_keys_and_permutation(oracle):
+    keys = oracle.data_shuffle_keys(44, 3, 11)
+    for i in range(11):   # known answer: word i&3 of the Philox block with counter (i>>2, 0, epoch lo, epoch hi)
+        assert keys[i] == int(oracle.philox_raw([44, 0], [i >> 2, 0, 3, 0])[i & 3] >> 1)
+    p0, p0b, p1 = oracle.data_shuffle_perm(44, 0, 1000), oracle.data_shuffle_perm(44, 0, 1000), oracle.data_shuffle_perm(44, 1, 1000)
+    assert np.array_equal(np.sort(p0), np.arange(1000)) and np.array_equal(p0, p0b) and not np.array_equal(p0, p1)
+    assert oracle.data_shuffle_perm(1, 0, 0).size == 0
+
+
+def test_oracle_gather_unpacks_the_mnist_fixture(oracle):
+    bits = golden("data_mnist01_t10k_bits.npz")["bits"]
+    idx = np.array([5, 0, 77, 5])
+    rows = oracle.data_gather(bits, idx, bits_visible=784, out_dtype=np.uint8)
+    assert rows.shape == (4, 784) and np.array_equal(rows, np.unpackbits(bits[idx], axis=1)[:, :784])
+    x, lab, one = oracle.data_gather(np.arange(12, dtype=np.float32).reshape(4, 3), [2, 1], labels=[0, 1, 2, 1], num_classes=3)
+    assert np.array_equal(x, [[6, 7, 8], [3, 4, 5]]) and np.array_equal(lab, [2, 1]) and np.array_equal(one, [[0, 0, 1], [0, 1, 0]])
+
+
+@pytest.mark.parametrize("storage,out", [("f32", "f32"), ("u8", "u8"), ("bits", "u8"), ("bits", "f32")])
+def test_device_dataset_host_logic(oracle, storage, out):
+    from oracle_backends import OracleDataOps
+    from qbm_image_classification_amd.device_data import DeviceDataset
+
+    x, y = _set()
+    want = x if storage == "f32" else (x > 0.5).astype(np.float32)
+    ds = DeviceDataset(x, y, batch_size=8, num_classes=3, storage=storage, out=out, seed=9, ops=OracleDataOps())
+    assert len(ds) == 5 and ds.epoch == 0
+    seen = []
+    for ep in range(2):
+        perm = oracle.data_shuffle_perm(9, ep, 37)
+        got = list(ds)
+        assert [len(b) for b, _ in got] == [8, 8, 8, 8, 5] and ds.epoch == ep + 1
+        xb = torch.cat([b for b, _ in got]).numpy().astype(np.float32)
+        lb = torch.cat([l for _, l in got]).numpy()
+        assert np.array_equal(xb, want[perm]) and np.array_equal(lb, y[perm]) and got[0][1].dtype == torch.int64
+        seen.append(perm)
+    assert not np.array_equal(seen[0], seen[1])
+    # two ranks together deliver exactly the single-process batches of 16
+    whole = DeviceDataset(x, y, batch_size=16, num_classes=3, storage=storage, out=out, seed=9, ops=OracleDataOps())
+    r0 = DeviceDataset(x, y, batch_size=8, num_classes=3, storage=storage, out=out, seed=9, rank=0, world=2, ops=OracleDataOps())
+    r1 = DeviceDataset(x, y, batch_size=8, num_classes=3, storage=storage, out=out, seed=9, rank=1, world=2, ops=OracleDataOps())
+    assert len(whole) == len(r0) == len(r1) == 3
+    for (xw, lw, ow), (x0, l0, _), (x1, l1, _) in zip(whole.batches(0, True), r0.batches(0), r1.batches(0)):
+        assert torch.equal(xw, torch.cat([x0, x1])) and torch.equal(lw, torch.cat([l0, l1]))
+        assert torch.equal(ow.argmax(1).int(), lw)
+    assert [len(b[0]) for b in r1.batches(0)] == [8, 8, 0]      # 37 = 16 + 16 + 5: the last global batch holds 5 rows
+    # no shuffle, drop_last
+    plain = DeviceDataset(x, y, batch_size=8, num_classes=3, storage=storage, out=out, shuffle=False, drop_last=True, ops=OracleDataOps())
+    assert len(plain) == 4 and np.array_equal(next(iter(plain))[1].numpy(), y[:8])
+    with pytest.raises(ValueError):
+        DeviceDataset(x, y, batch_size=8, num_classes=3, storage="f32", out="u8", ops=OracleDataOps())
+
+
+# ---- GPU: HIP entry points vs the oracle ---------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def dops():
+    from qbm_image_classification_amd.device_data import HipDataOps
+
+    return HipDataOps("cuda:0")
+
+
+@pytest.mark.gpu
+def test_hip_shuffle_pack_binarise_bitwise(dops, oracle):
+    for n in (1, 5, 37, 2115, 60000):
+        assert np.array_equal(dops.shuffle_keys(44, 7, n).cpu().numpy(), oracle.data_shuffle_keys(44, 7, n))
+        assert np.array_equal(dops.permutation(44, 7, n).cpu().numpy(), oracle.data_shuffle_perm(44, 7, n))
+    x, _ = _set(50, 13)
+    xb = dops.binarise(torch.from_numpy(x), 0.5)
+    assert np.array_equal(xb.cpu().numpy(), (x > 0.5).astype(np.uint8))
+    assert np.array_equal(dops.pack_bits(xb).cpu().numpy(), np.packbits((x > 0.5).astype(np.uint8), axis=1))
+    f = golden("data_mnist01_t10k_bits.npz")
+    full = np.unpackbits(f["bits"], axis=1)[:, :784]
+    assert np.array_equal(dops.pack_bits(torch.from_numpy(full)).cpu().numpy(), f["bits"])   # 98 B per image
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("V", [784, 13])
+def test_hip_gather_all_kinds(dops, oracle, V):
+    x, y = _set(300, V, classes=10, seed=3)
+    xb = (x > 0.5).astype(np.uint8)
+    idx = np.random.RandomState(1).randint(0, 300, 129)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dops.device)
+    lab = t(y.astype(np.int32))
+    srcs = {0: (t(x), x, None), 1: (t(xb), xb, None), 2: (t(np.packbits(xb, axis=1)), np.packbits(xb, axis=1), V)}
+    for sk, (dev_src, host_src, bv) in srcs.items():
+        for dk, dt in ((0, np.float32), (1, np.uint8)):
+            if sk == 0 and dk == 1:
+                continue    # fp32 greyscale -> uint8 is defined for binary data only
+            got, gl, go = dops.gather(dev_src, sk, t(idx.astype(np.int32)), V, dk, lab, 10, True)
+            wx, wl, wo = oracle.data_gather(host_src, idx, y, 10, bv, dt)
+            assert got.dtype == (torch.float32 if dk == 0 else torch.uint8)
+            assert np.array_equal(got.cpu().numpy(), wx) and np.array_equal(gl.cpu().numpy(), wl) and np.array_equal(go.cpu().numpy(), wo)
+    got, gl, go = dops.gather(srcs[1][0], 1, t(idx[:3].astype(np.int32)), V, 1)
+    assert gl is None and go is None and np.array_equal(got.cpu().numpy(), xb[idx[:3]])
+
+
+@pytest.mark.gpu
+def test_training_from_device_dataset_equals_manual_batches(dops):
+    """ClassificationRBM.train_rbm fed by DeviceDataset (bit-packed storage, uint8 minibatches) ends with the same
+    parameters, bit for bit, as the same batches gathered on the host and passed in as fp32."""
+    from qbm_image_classification_amd.classification_rbm import ClassificationRBM
+    from qbm_image_classification_amd.device_data import DeviceDataset
+
+    x, y = _set(70, 784, classes=2, seed=5)
+    xb = (x > 0.5).astype(np.float32)
+
+    def model():
+        return ClassificationRBM(784, 32, 1, num_classes=2, learning_rate=0.05, seed=1, device="cuda:0")
+
+    a = model()
+    ds = DeviceDataset(x, y, batch_size=16, num_classes=2, storage="bits", seed=3)
+    assert ds.bytes_resident() == 70 * 98 + 70 * 4
+    a.train_rbm(ds, epochs=2, method="hybrid")
+    b = model()
+    manual = []
+    for ep in range(2):
+        perm = ds.ops.permutation(3, ep, 70).cpu().numpy()
+        manual.append([(torch.from_numpy(xb[perm[i:i + 16]]), torch.from_numpy(y[perm[i:i + 16]])) for i in range(0, 70, 16)])
+
+    class Loader:
+        def __init__(self):
+            self.ep = 0
+
+        def __len__(self):
+            return 5
+
+        def __iter__(self):
+            self.ep += 1
+            return iter(manual[self.ep - 1])
+
+    b.train_rbm(Loader(), epochs=2, method="hybrid")
+    for nm in ("weights", "visible_bias", "hidden_bias", "class_weights", "class_bias"):
+        assert torch.equal(getattr(a, nm), getattr(b, nm)), nm

@@ -65,6 +65,22 @@ def main():
         us = timeit(lambda: ops.free_energy(P, x))
         out.append({"what": f"sample_class_given_x 784x512 B=256 C={C} (reference CPU: 29/108 ms)", "us_per_call": round(us, 2)})
         print(json.dumps(out[-1]), flush=True)
+    # a whole epoch from the device-resident dataset: permutation + one gather launch per step, no host copies
+    from qbm_image_classification_amd.device_data import DeviceDataset
+
+    V, H, C, B, N = 784, 512, 10, 256, 60160
+    rs = np.random.RandomState(0)
+    ds = DeviceDataset((rs.random_sample((N, V)) < 0.2).astype(np.uint8), rs.randint(0, C, N), B, C, storage="bits", seed=1)
+    P = params(ops, V, H, C); G = GradSet(V, H, C, ops.device); ws = ops.cd_workspace(P, B)
+    for rep in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for k, (xb, lab, one) in enumerate(ds.batches(rep, True)):
+            ops.cd_step(P, G, xb, one, 1, 7, (rep * len(ds) + k) * 4, 0, None, None, True, 0.05, 1.0, float(B), 0.0, ws)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    out.append({"what": f"epoch of {N} bit-packed images ({ds.bytes_resident() / 1e6:.1f} MB resident), CD-1 784x512 B=256, "
+                        "device permutation + gather per step", "ms_per_epoch": round(dt * 1e3, 2),
+                "us_per_step": round(dt / len(ds) * 1e6, 2), "images_per_s": round(N / dt, 1)})
+    print(json.dumps(out[-1]), flush=True)
     # one Disc_QBM training minibatch at config #5 (both phases, fields, statistics, host update)
     from qbm_image_classification_amd.disc_qbm import Disc_QBM
 
