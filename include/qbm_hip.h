@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QBM_ABI_VERSION 4
+#define QBM_ABI_VERSION 5
 #define QBM_MAX_CLASSES 15 /* class rows + the bias row share one 16-row gradient tile */
 #define QBM_MAX_QUBO_VARS 1024
 
@@ -213,6 +213,17 @@ QBM_API int qbm_data_shuffle_keys(uint64_t seed, uint64_t epoch, int N, int32_t*
  * y1hot[B,C].  idx values must lie in [0, N). */
 QBM_API int qbm_data_gather(const void* src, int src_kind, const int32_t* idx, int B, int V, void* dst, int dst_kind,
                             const int32_t* labels, int32_t* labels_out, float* y1hot, int C, void* stream);
+
+/* ---- greedy k-center coreset --------------------------------------------
+ * src/coreset.py:28-106 k_center_greedy with the Euclidean metric (euclidean_dist :6-13), whose embeddings are the
+ * hidden means the path already produces.  embT is the embedding matrix TRANSPOSED, [D,N] fp32 on the device;
+ * seeds_host (HOST array, n_seeds >= 1) are the centres already chosen (:64-67 the random first centre, or
+ * `already_selected`); n_picks further centres are chosen (the first pick re-selects a seed, exactly as the
+ * reference's +inf / argmax step does, :89, :94).  picks[n_picks] int32 and selected[N] uint8 (the final mask,
+ * seeds included) are device outputs.  workspace: qbm_kcenter_workspace_bytes(N, n_seeds) bytes of device memory. */
+QBM_API long qbm_kcenter_workspace_bytes(int N, int n_seeds);
+QBM_API int qbm_kcenter_greedy(const float* embT, int N, int D, const int32_t* seeds_host, int n_seeds, int n_picks,
+                               int32_t* picks, uint8_t* selected, void* workspace, void* stream);
 
 /* ---- Disc_QBM: QUBO sampler ------------------------------------------------------------------ */
 

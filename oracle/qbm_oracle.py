@@ -105,6 +105,41 @@ def data_gather(x, idx, labels=None, num_classes=0, bits_visible=None, out_dtype
     return rows, lab, onehot
 
 
+def kcenter_picks(emb, seeds, n_picks):
+    """orc_kcenter_greedy: (picks int32 [n_picks], selected uint8 [N]) for given seed centres."""
+    emb = _f32(emb)
+    n, d = emb.shape
+    seeds = np.ascontiguousarray(seeds, dtype=np.int32)
+    picks = np.empty(n_picks, np.int32)
+    sel = np.empty(n, np.uint8)
+    i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    f = lib().orc_kcenter_greedy
+    f.argtypes = [_f32p, C.c_int, C.c_int, i32p, C.c_int, C.c_int, i32p, np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")]
+    f.restype = None
+    f(emb, n, d, seeds, len(seeds), n_picks, picks, sel)
+    return picks, sel
+
+
+def k_center_greedy(embedding_matrix, budget, random_seed=None, index=None, already_selected=None):
+    """src/coreset.py:28-106 restated around orc_kcenter_greedy (budget bookkeeping :38-44, seed centre :64-67,
+    result = index[select_mask] :106)."""
+    emb = _f32(embedding_matrix)
+    n = emb.shape[0]
+    budget = min(budget + 1, n)
+    index = np.arange(n) if index is None else np.asarray(index)
+    sel = [] if already_selected is None else list(already_selected)
+    np.random.seed(random_seed)
+    if len(sel) == 0:
+        sel = [int(np.random.randint(0, n))]
+    mask = np.zeros(n, bool)
+    mask[sel] = True
+    remaining = budget - int(mask.sum())
+    if remaining <= 0:
+        return index[mask]
+    _, selected = kcenter_picks(emb, np.flatnonzero(mask), remaining)
+    return index[selected.astype(bool)]
+
+
 def math(which: str, x) -> np.ndarray:
     x = _f32(x)
     y = np.empty_like(x)

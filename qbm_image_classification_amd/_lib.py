@@ -8,7 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libqbm_hip.so")
 
-QBM_ABI_VERSION = 4
+QBM_ABI_VERSION = 5
 QBM_MAX_CLASSES = 15
 QBM_F32, QBM_U8 = 0, 1
 
@@ -67,6 +67,8 @@ SIGNATURES = {
     "qbm_data_pack_bits": [_p, _i, _i, _p, _p],
     "qbm_data_shuffle_keys": [_u64, _u64, _i, _p, _p],
     "qbm_data_gather": [_p, _i, _p, _i, _i, _p, _i, _p, _p, _p, _i, _p],
+    "qbm_kcenter_workspace_bytes": [_i, _i],
+    "qbm_kcenter_greedy": [_p, _i, _i, C.POINTER(C.c_int32), _i, _i, _p, _p, _p, _p],
     "qbm_test_math": [_i, _p, _p, _i, _p],
     "qbm_test_uniform": [_u64, _u64, _u32, _i, _i, _p, _p],
     "qbm_qubo_gibbs": [_p, _p, _i, _i, _i, _i, _f, _f, _u64, _u64, _p, _p, _p],
@@ -94,7 +96,7 @@ def load() -> C.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name == "qbm_last_error" else C.c_int
+        fn.restype = C.c_char_p if name == "qbm_last_error" else C.c_long if name.endswith("_bytes") else C.c_int
     if lib.qbm_abi_version() != QBM_ABI_VERSION:
         raise QbmHipError(f"ABI mismatch: library {lib.qbm_abi_version()} vs binding {QBM_ABI_VERSION}")
     _lib = lib

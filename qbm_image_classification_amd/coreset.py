@@ -1,0 +1,97 @@
+"""Coreset selection: the HIP mirror of the reference's `src/coreset.py`.
+
+`k_center_greedy` keeps the reference's signature and bookkeeping (`src/coreset.py:28-106`: `budget += 1`, the
+random first centre from `np.random.seed(random_seed)`, `index[select_mask]` as the result) and runs the picks on
+the GPU through `qbm_kcenter_greedy` (one launch per pick).  Only the Euclidean metric of the reference
+(`euclidean_dist`, `:6-13`) is implemented; a custom `metric` callable is refused rather than silently ignored.
+`random_downsampling` (`:123-141`) is host-side numpy, as in the reference.  No CPU fallback for the picks."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, current_stream, ptr
+
+
+def euclidean_dist(x, y):
+    """The reference's metric (src/coreset.py:6-13), kept for callers that import it; torch, any device."""
+    m, n = x.size(0), y.size(0)
+    xx = torch.pow(x, 2).sum(1, keepdim=True).expand(m, n)
+    yy = torch.pow(y, 2).sum(1, keepdim=True).expand(n, m).t()
+    dist = xx + yy - 2.0 * (x @ y.t())
+    return dist.clamp(min=1e-12).sqrt()
+
+
+def kcenter_picks(emb, seeds, n_picks, device="cuda:0"):
+    """Device picks for given seed centres -> (picks int32 [n_picks], selected uint8 [N]) as device tensors."""
+    lib = _lib.load()
+    if not torch.cuda.is_available():
+        raise _lib.QbmHipError("no ROCm device visible: the HIP path cannot run (there is no CPU fallback)")
+    dev = torch.device(device)
+    emb = torch.as_tensor(emb).to(dev, torch.float32)
+    n, d = emb.shape
+    embT = emb.t().contiguous()
+    seeds = np.ascontiguousarray(seeds, dtype=np.int32)
+    ws = torch.empty(lib.qbm_kcenter_workspace_bytes(n, len(seeds)), dtype=torch.uint8, device=dev)
+    picks = torch.empty(max(n_picks, 1), dtype=torch.int32, device=dev)
+    selected = torch.empty(n, dtype=torch.uint8, device=dev)
+    check(lib.qbm_kcenter_greedy(ptr(embT), n, d, seeds.ctypes.data_as(C.POINTER(C.c_int32)), len(seeds), n_picks, ptr(picks),
+                                 ptr(selected), ptr(ws), current_stream()), "qbm_kcenter_greedy")
+    return picks[:n_picks], selected
+
+
+def k_center_greedy(embedding_matrix, budget: int, metric=euclidean_dist, device=None, random_seed=None, index=None,
+                    already_selected=None, print_freq: int = 20):
+    """src/coreset.py:28-106 -> index[select_mask] (numpy), exactly `budget` entries when budget < N."""
+    if isinstance(embedding_matrix, np.ndarray):
+        assert embedding_matrix.ndim == 2
+    elif isinstance(embedding_matrix, torch.Tensor):
+        assert embedding_matrix.dim() == 2
+    else:
+        raise TypeError("embedding_matrix must be np.ndarray or torch.Tensor")
+    if not callable(metric):
+        raise ValueError("metric must be callable")
+    if metric is not euclidean_dist:
+        raise NotImplementedError("the HIP k-center path implements the reference's euclidean_dist only")
+    budget += 1
+    sample_num = int(embedding_matrix.shape[0])
+    if budget < 0:
+        raise ValueError("Illegal budget size.")
+    if budget > sample_num:
+        budget = sample_num
+    if index is not None:
+        assert sample_num == len(index)
+        index = np.asarray(index)
+    else:
+        index = np.arange(sample_num)
+    already_selected = [] if already_selected is None else list(already_selected)
+    np.random.seed(random_seed)
+    select_mask = np.zeros(sample_num, dtype=bool)
+    if len(already_selected) == 0:
+        already_selected = [np.random.randint(0, sample_num)]
+    select_mask[already_selected] = True
+    remaining_budget = budget - int(select_mask.sum())
+    if remaining_budget <= 0:
+        return index[select_mask]
+    dev = "cuda:0" if device is None or torch.device(device).type != "cuda" else device
+    _, selected = kcenter_picks(embedding_matrix, np.flatnonzero(select_mask), remaining_budget, dev)
+    return index[selected.cpu().numpy().astype(bool)]
+
+
+def downsample_kcenter(embeddings, train_x, train_y, budget: int, random_seed: int):
+    """src/coreset.py:109-120 with the embeddings passed in (the reference takes them from Conv_Deep_QBM, out of scope;
+    for the RBM / Disc_QBM path they are the hidden means p(h|x))."""
+    idx = k_center_greedy(embeddings, budget=budget, random_seed=random_seed)
+    return train_x[idx], train_y[idx]
+
+
+def random_downsampling(x, y, downsample_size, seed: int = 42):
+    """src/coreset.py:123-141"""
+    if len(x) < downsample_size:
+        raise ValueError("Downsample size must be less than the number of samples in the dataset.")
+    np.random.seed(seed)
+    indices = np.random.choice(len(x), downsample_size, replace=False)
+    return x[indices], y[indices]

@@ -81,6 +81,17 @@ def main():
                         "device permutation + gather per step", "ms_per_epoch": round(dt * 1e3, 2),
                 "us_per_step": round(dt / len(ds) * 1e6, 2), "images_per_s": round(N / dt, 1)})
     print(json.dumps(out[-1]), flush=True)
+    # greedy k-center coreset at the size config #5 draws from (MNIST 0/1 train split, 256-d hidden means)
+    from qbm_image_classification_amd import coreset
+
+    emb = torch.rand(12665, 256, device=ops.device)
+    coreset.kcenter_picks(emb, [0], 10)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    coreset.kcenter_picks(emb, [0], 1001)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    out.append({"what": "k_center_greedy 12665 x 256 embeddings, 1000 centres (one launch per pick)", "ms": round(dt * 1e3, 2),
+                "us_per_pick": round(dt / 1001 * 1e6, 2)})
+    print(json.dumps(out[-1]), flush=True)
     # one Disc_QBM training minibatch at config #5 (both phases, fields, statistics, host update)
     from qbm_image_classification_amd.disc_qbm import Disc_QBM
 

@@ -330,6 +330,16 @@ def gen_coreset():
             idx = coreset.k_center_greedy(torch.from_numpy(emb), budget=20, random_seed=3)
         np.savez_compressed(os.path.join(OUT, "coreset_small.npz"), emb=emb, budget=20, random_seed=3,
                             idx=np.asarray(idx))
+        # a second, larger case: hidden-mean-like embeddings in [0,1], given first centres and a custom index array
+        emb2 = (1.0 / (1.0 + np.exp(-rs.standard_normal((600, 32)) * 2.0))).astype(np.float32)
+        index2 = np.arange(600)[::-1].copy()
+        with warnings.catch_warnings(), contextlib.redirect_stdout(io.StringIO()):
+            warnings.simplefilter("ignore")
+            idx2 = coreset.k_center_greedy(torch.from_numpy(emb2), budget=75, random_seed=11)
+            idx3 = coreset.k_center_greedy(emb2, budget=40, random_seed=5, index=index2, already_selected=[3, 17, 599])
+        xs, ys = coreset.random_downsampling(np.arange(50) * 2, np.arange(50), 7, seed=42)
+        np.savez_compressed(os.path.join(OUT, "coreset_mid.npz"), emb=emb2, idx_budget75_seed11=np.asarray(idx2),
+                            index=index2, idx_budget40_seed5_given=np.asarray(idx3), random_down_x=xs, random_down_y=ys)
     finally:
         os.chdir(cwd)
         for m in stubs:
