@@ -137,6 +137,9 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
         }
         if (MODE == 0 && (a.s || a.s8))
             uu[op] = uniform4(a.seed, a.offset, a.row0 + (uint32_t)(m0 + SO::row(op)), (uint32_t)(j0 >> 2));
+        // keep the draw here (the compiler would sink ~100 VALU instructions into the epilogue, behind the contraction):
+        // this way it runs while the loads above and the first LDS-DMA transfers are in flight
+        asm volatile("" : "+v"(uu[op]));
     }
     const auto o = strip_mma<MT, NT, FAST, FAST>(A, Bv, m0, n0, a.V, lds, a.KP);
 #pragma unroll
@@ -310,6 +313,7 @@ __global__ __launch_bounds__(256) void k_visible(VisibleArgs a)
         }
         uu[op] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (a.s || a.s8) uu[op] = uniform4(a.seed, a.offset, a.row0 + (uint32_t)(m0 + SO::row(op)), (uint32_t)(k0 >> 2));
+        asm volatile("" : "+v"(uu[op]));   // pinned in front of the contraction (see k_hidden)
     }
     const auto o = strip_mma<MT, NT, FAST, FAST>(A, Bv, m0, n0, a.H, lds, a.KP);
 #pragma unroll
