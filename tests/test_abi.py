@@ -57,7 +57,18 @@ def test_product_has_no_cpu_fallback():
         pytest.skip("GPU present")
     with pytest.raises(QbmHipError):
         ClassificationRBM(16, 8, 1)
-    src = open(os.path.join(ROOT, "qbm_image_classification_amd", "rbm_ops.py")).read()
-    for mod in ("classification_rbm.py", "disc_qbm.py", "sampler.py", "rbm_ops.py", "_lib.py", "data_loader.py"):
-        text = open(os.path.join(ROOT, "qbm_image_classification_amd", mod)).read()
-        assert "import oracle" not in text and "from oracle" not in text and "qbm_oracle" not in text
+    import glob
+
+    mods = glob.glob(os.path.join(ROOT, "qbm_image_classification_amd", "*.py")) + [os.path.join(ROOT, "rbm_main.py"),
+                                                                                    os.path.join(ROOT, "qbm_main.py")]
+    assert len(mods) >= 12
+    for mod in mods:     # nothing shipped may import, call or link the oracle
+        text = open(mod).read()
+        assert "import oracle" not in text and "from oracle" not in text and "qbm_oracle" not in text, mod
+    # the HIP-backed entry points of the "next" rows refuse to run without the library / device too
+    from qbm_image_classification_amd import coreset, device_data
+
+    with pytest.raises(QbmHipError):
+        device_data.HipDataOps("cuda:0")
+    with pytest.raises(QbmHipError):
+        coreset.k_center_greedy(__import__("numpy").zeros((8, 2), "float32"), 3, random_seed=0)
