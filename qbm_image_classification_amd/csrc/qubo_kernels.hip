@@ -24,17 +24,84 @@ namespace {
 // instead of 64 serial ones; results are bit-identical to the serial order.
 // Uniforms come from Philox (row = chain id, col = spin), one draw id per sweep.
 // ---------------------------------------------------------------------------------------------
-template <int NF>
-__global__ __launch_bounds__(256) void k_qubo_gibbs(const float* __restrict__ lin, const float* __restrict__ J,
-                                                    int nchains, int R, int n, int sweeps, float beta0,
-                                                    float beta1, uint64_t seed, uint64_t offset,
-                                                    uint8_t* __restrict__ states)
+// J row readers.  The couplings are symmetric (J = Q_offdiag + Q_offdiag^T, include/qbm_hip.h), so a workgroup can
+// keep the upper triangle (diagonal included) in LDS: n(n+1)/2 floats, 132.6 KB at n = 257.  Every flip reads one row
+// of J; from L2 that read (1 KB, on the critical path of the chain) is what bounds the sweep -- 12 G spin updates/s
+// hot vs 156 G cold -- from LDS it costs a few bank-conflicted cycles.
+//   T(r, c) = tri[S(r) + c - r],  r <= c,  S(r) = r n - r (r - 1) / 2.
+// row<T>(p, ...): the row of spin p, which lies in tile T (compile-time in the unrolled sweep).  Lanes beyond n
+// ("phantom" spins of the last tile) get some finite value: their fields are never tested, flipped or stored.
+struct JGlobal {
+    const float* J;
+    int n;
+    __device__ __forceinline__ void setup(int) {}
+    template <int T, int NF>
+    __device__ __forceinline__ void row(int p, int lane, float (&out)[NF]) const
+    {
+        const float* Jr = J + (long)p * n;
+#pragma unroll
+        for (int tt = 0; tt < NF; ++tt) out[tt] = Jr[min(64 * tt + lane, n - 1)];
+    }
+};
+
+template <int NFT>
+struct JTri {
+    const float* tri;   // LDS
+    int n;
+    int ci[NFT];        // S(i) - i of this lane's spins: T(i, p) = tri[ci + p] for i < p
+    int ic[NFT];        // this lane's spin indices, clamped to n - 1
+    __device__ __forceinline__ void setup(int lane)
+    {
+#pragma unroll
+        for (int tt = 0; tt < NFT; ++tt) {
+            const int i = min(64 * tt + lane, n - 1);
+            ic[tt] = i;
+            ci[tt] = i * n - (i * (i - 1)) / 2 - i;
+        }
+    }
+    template <int T, int NF>
+    __device__ __forceinline__ void row(int p, int lane, float (&out)[NF]) const
+    {
+        const int up = p * n - (p * (p - 1)) / 2 - p;   // wave-uniform: T(p, i) = tri[up + i] for i >= p
+#pragma unroll
+        for (int tt = 0; tt < NF; ++tt) {
+            int ad;
+            if (tt < T) ad = ci[tt] + p;                 // every spin of an earlier tile is below p
+            else if (tt > T) ad = up + ic[tt];           // every spin of a later tile is above p
+            else ad = (ic[tt] >= p) ? up + ic[tt] : ci[tt] + p;
+            out[tt] = tri[ad];
+        }
+    }
+};
+
+// jr.row<T>() with the (unrolled, hence constant-folded) tile index t of the flipping spin
+template <int NF, class JR>
+__device__ __forceinline__ void row_of_tile(const JR& jr, int t, int p, int lane, float (&out)[NF])
 {
-    const int lane = threadIdx.x & 63;
-    const int ch = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (ch >= nchains) return;
+    if constexpr (NF <= 8) {
+        switch (t) {
+        case 0: jr.template row<0>(p, lane, out); break;
+        case 1: if constexpr (NF > 1) jr.template row<1>(p, lane, out); break;
+        case 2: if constexpr (NF > 2) jr.template row<2>(p, lane, out); break;
+        case 3: if constexpr (NF > 3) jr.template row<3>(p, lane, out); break;
+        case 4: if constexpr (NF > 4) jr.template row<4>(p, lane, out); break;
+        case 5: if constexpr (NF > 5) jr.template row<5>(p, lane, out); break;
+        case 6: if constexpr (NF > 6) jr.template row<6>(p, lane, out); break;
+        default: if constexpr (NF > 7) jr.template row<7>(p, lane, out); break;
+        }
+    } else {
+        jr.template row<0>(p, lane, out);   // only the L2 reader is instantiated this wide; it ignores the tile
+    }
+}
+
+// One chain (image b, read r) on one wavefront.
+template <int NF, class JR>
+__device__ __forceinline__ void gibbs_chain(const float* __restrict__ lin, const JR& jr, int ch, int R, int n, int sweeps,
+                                            float beta0, float beta1, uint64_t seed, uint64_t offset,
+                                            uint8_t* __restrict__ states, int lane)
+{
     const int b = ch / R;
-    float F[NF], thr[NF];
+    float F[NF], thr[NF], jrow[NF];
     bool st[NF];   // this lane's spin of tile t
 
     // start state s_i = (u < 0.5), draw id `offset`
@@ -56,12 +123,9 @@ __global__ __launch_bounds__(256) void k_qubo_gibbs(const float* __restrict__ li
         while (m) {
             const int j = 64 * t + __builtin_ctzll(m);
             m &= m - 1;
-            const float* Jr = J + (long)j * n;
+            row_of_tile<NF>(jr, t, j, lane, jrow);
 #pragma unroll
-            for (int tt = 0; tt < NF; ++tt) {
-                const int i = 64 * tt + lane;
-                if (i < n) F[tt] = F[tt] + Jr[i];
-            }
+            for (int tt = 0; tt < NF; ++tt) F[tt] = F[tt] + jrow[tt];
         }
     }
 
@@ -91,12 +155,9 @@ __global__ __launch_bounds__(256) void k_qubo_gibbs(const float* __restrict__ li
                 const int l = __builtin_ctzll(want);              // first spin that flips; the ones before it stay
                 const bool was = (__ballot(st[t]) >> l) & 1ull;
                 const float sg = was ? -1.0f : 1.0f;
-                const float* Jr = J + (long)(64 * t + l) * n;
+                row_of_tile<NF>(jr, t, 64 * t + l, lane, jrow);
 #pragma unroll
-                for (int tt = 0; tt < NF; ++tt) {
-                    const int i = 64 * tt + lane;
-                    if (i < n) F[tt] = __builtin_fmaf(sg, Jr[i], F[tt]);
-                }
+                for (int tt = 0; tt < NF; ++tt) F[tt] = __builtin_fmaf(sg, jrow[tt], F[tt]);
                 if (lane == l) st[t] = !was;
                 pending = (l >= 63) ? 0ull : (pending & (~0ull << (l + 1)));
             }
@@ -107,6 +168,46 @@ __global__ __launch_bounds__(256) void k_qubo_gibbs(const float* __restrict__ li
         const int i = 64 * t + lane;
         if (i < n) states[(long)ch * n + i] = st[t] ? 1 : 0;
     }
+}
+
+// J rows from L2 (any n <= QBM_MAX_QUBO_VARS): 4 chains per workgroup
+template <int NF>
+__global__ __launch_bounds__(256) void k_qubo_gibbs(const float* __restrict__ lin, const float* __restrict__ J,
+                                                    int nchains, int R, int n, int sweeps, float beta0,
+                                                    float beta1, uint64_t seed, uint64_t offset,
+                                                    uint8_t* __restrict__ states)
+{
+    const int lane = threadIdx.x & 63;
+    const int ch = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (ch >= nchains) return;
+    JGlobal jr{J, n};
+    jr.setup(lane);
+    gibbs_chain<NF>(lin, jr, ch, R, n, sweeps, beta0, beta1, seed, offset, states, lane);
+}
+
+// J triangle in LDS: one workgroup of 16 wavefronts per CU, every wavefront walks chains ch = wave id, + total waves, ...
+constexpr int kGibbsLdsWaves = 16;
+template <int NF>
+__global__ __launch_bounds__(64 * kGibbsLdsWaves) void k_qubo_gibbs_lds(const float* __restrict__ lin,
+                                                                        const float* __restrict__ J, int nchains, int R,
+                                                                        int n, int sweeps, float beta0, float beta1,
+                                                                        uint64_t seed, uint64_t offset,
+                                                                        uint8_t* __restrict__ states)
+{
+    extern __shared__ float tri[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    for (int r = w; r < n; r += (int)blockDim.x >> 6) {
+        const int S = r * n - (r * (r - 1)) / 2;
+        for (int c = r + lane; c < n; c += 64) tri[S + c - r] = J[(long)r * n + c];
+    }
+    __syncthreads();
+    JTri<NF> jr{tri, n, {}, {}};
+    jr.setup(lane);
+    const int waves = (int)blockDim.x >> 6;
+    const int total = gridDim.x * waves;
+    for (int ch = blockIdx.x * waves + w; ch < nchains; ch += total)
+        gibbs_chain<NF>(lin, jr, ch, R, n, sweeps, beta0, beta1, seed, offset, states, lane);
 }
 
 // mean over reads, float64: exact count / R  (np.average(np_samples, axis=0) on {0,1} samples,
@@ -189,6 +290,24 @@ int launch_gibbs(const float* lin, const float* J, int B, int R, int n, int swee
                  uint64_t seed, uint64_t offset, uint8_t* states, hipStream_t st)
 {
     const int nch = B * R;
+    const size_t tri_bytes = (size_t)n * (n + 1) / 2 * sizeof(float);
+    if (NF <= 5 && tri_bytes <= 150 * 1024 && nch >= 64) {
+        // the triangle of J fits the LDS of a CU (n <= 276): one persistent workgroup per CU, rows of J read from LDS
+        if (tri_bytes > 65536) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_qubo_gibbs_lds<NF>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)tri_bytes);
+            if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_qubo_gibbs_lds)");
+        }
+        // one workgroup per CU (256), as many wavefronts as even out the rounds: every wave walks `rounds` chains
+        const int wgs = nch < 256 * 4 ? (nch + 3) / 4 : 256;
+        const int rounds = (nch + wgs * kGibbsLdsWaves - 1) / (wgs * kGibbsLdsWaves);
+        int waves = (nch + rounds * wgs - 1) / (rounds * wgs);
+        waves = waves < 1 ? 1 : waves > kGibbsLdsWaves ? kGibbsLdsWaves : waves;
+        hipLaunchKernelGGL((k_qubo_gibbs_lds<NF>), dim3(wgs), dim3(64 * waves), tri_bytes, st, lin, J, nch, R, n, sweeps,
+                           beta0, beta1, seed, offset, states);
+        QBM_CHECK_LAUNCH("k_qubo_gibbs_lds");
+        return QBM_OK;
+    }
     hipLaunchKernelGGL((k_qubo_gibbs<NF>), dim3((nch + 3) / 4), dim3(256), 0, st, lin, J, nch, R, n, sweeps, beta0,
                        beta1, seed, offset, states);
     QBM_CHECK_LAUNCH("k_qubo_gibbs");
