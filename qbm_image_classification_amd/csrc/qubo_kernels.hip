@@ -133,15 +133,23 @@ __device__ __forceinline__ void gibbs_chain(const float* __restrict__ lin, const
     for (int sw = 1; sw <= sweeps; ++sw) {
         float beta = beta1;
         if (sweeps > 1) beta = beta0 * det_expf(lr * ((float)(sw - 1) / (float)(sweeps - 1)));
+        // Uniforms of this sweep.  Spin i takes word i&3 of Philox block i>>2, so the 64 spins of a tile share 16
+        // blocks: one pass in which lane L computes block 64*pass + L serves four tiles, and each spin fetches its word
+        // from lane 16*(t&3) + (lane>>2) (ds_bpermute) -- a quarter of the Philox work of one call per spin.
+        constexpr int NPASS = (NF + 3) / 4;
+        f32x4 ub[NPASS];
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps)
+            ub[ps] = uniform4(seed, offset + (uint64_t)sw, (uint32_t)ch, (uint32_t)(64 * ps + lane));
 #pragma unroll
         for (int t = 0; t < NF; ++t) {
             const int i = 64 * t + lane;
-            thr[t] = 0.f;
-            if (i < n) {
-                const f32x4 u4 = uniform4(seed, offset + (uint64_t)sw, (uint32_t)ch, (uint32_t)(i >> 2));
-                const float u = u4[i & 3];
-                thr[t] = -(det_logf(u) - det_logf(1.0f - u));
-            }
+            const int src = 16 * (t & 3) + (lane >> 2);
+            const float w0 = __shfl(ub[t >> 2][0], src, kWave), w1 = __shfl(ub[t >> 2][1], src, kWave);
+            const float w2 = __shfl(ub[t >> 2][2], src, kWave), w3 = __shfl(ub[t >> 2][3], src, kWave);
+            const int k = lane & 3;
+            const float u = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? w2 : w3;
+            thr[t] = (i < n) ? -(det_logf(u) - det_logf(1.0f - u)) : 0.f;
         }
 #pragma unroll
         for (int t = 0; t < NF; ++t) {
