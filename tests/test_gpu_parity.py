@@ -257,8 +257,13 @@ def test_qubo_gibbs_bitwise(oracle):
 
     q = HipQuboOps("cuda:0")
     rs = np.random.RandomState(3)
+    # fewer than 64 chains or n > 276: J rows from L2 (k_qubo_gibbs); otherwise the LDS-resident triangle
+    # (k_qubo_gibbs_lds, persistent workgroups: more chains than wavefronts makes every wave walk several)
     for (B, R, n, sweeps, b0, b1) in [(3, 5, 7, 4, 1.0, 1.0), (2, 10, 65, 6, 0.1, 3.0), (4, 7, 257, 3, 1.0, 1.0),
-                                      (1, 3, 300, 2, 0.5, 2.0), (2, 4, 1, 3, 1.0, 1.0)]:
+                                      (1, 3, 300, 2, 0.5, 2.0), (2, 4, 1, 3, 1.0, 1.0),
+                                      (8, 16, 257, 3, 0.2, 2.0), (4, 32, 65, 5, 1.0, 1.0), (2, 40, 276, 2, 0.5, 1.5),
+                                      (70, 1, 7, 4, 1.0, 1.0), (150, 40, 33, 2, 0.3, 3.0), (2, 40, 277, 2, 0.5, 1.5),
+                                      (1, 70, 700, 2, 0.7, 1.3)]:
         lin = rs.standard_normal((B, n)).astype(np.float32)
         Ju = np.triu(rs.standard_normal((n, n)).astype(np.float32) * 0.3, 1)
         J = (Ju + Ju.T).astype(np.float32)
