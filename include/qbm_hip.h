@@ -220,7 +220,9 @@ QBM_API int qbm_data_gather(const void* src, int src_kind, const int32_t* idx, i
  * seeds_host (HOST array, n_seeds >= 1) are the centres already chosen (:64-67 the random first centre, or
  * `already_selected`); n_picks further centres are chosen (the first pick re-selects a seed, exactly as the
  * reference's +inf / argmax step does, :89, :94).  picks[n_picks] int32 and selected[N] uint8 (the final mask,
- * seeds included) are device outputs.  workspace: qbm_kcenter_workspace_bytes(N, n_seeds) bytes of device memory. */
+ * seeds included) are device outputs.  workspace: qbm_kcenter_workspace_bytes(N, n_seeds) bytes of device memory.
+ * The one exception to the conventions above: seeds_host is read on the host and copied to the device inside the call
+ * (hipMemcpyAsync), so this entry point is not legal inside a stream capture. */
 QBM_API long qbm_kcenter_workspace_bytes(int N, int n_seeds);
 QBM_API int qbm_kcenter_greedy(const float* embT, int N, int D, const int32_t* seeds_host, int n_seeds, int n_picks,
                                int32_t* picks, uint8_t* selected, void* workspace, void* stream);
