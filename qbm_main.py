@@ -87,23 +87,28 @@ def _bool(s):
 
 
 if __name__ == '__main__':
-    parser = argparse.ArgumentParser(description='Discriminative QBM with a GPU Gibbs sampler.')
-    parser.add_argument('-hn', '--hnodes', metavar='INT', help='Amount of hidden units for RBM model', default=2, type=int)
-    parser.add_argument('-lr', '--learning_rate', metavar='FLOAT', help='Learning rate for training', default=0.4529451796571889, type=float)
-    parser.add_argument('-r', '--restricted', help='Restricted weights between hidden nodes', default=False, type=_bool)
-    parser.add_argument('-e', '--epochs', metavar='INT', help='Epochs fr training', default=20, type=int)
-    parser.add_argument('-b', '--batch_size', metavar='INT', help='Batchsize for training', default=73, type=int)
-    parser.add_argument('-s', '--seed', metavar='INT', help='Seed for RNG', default=3492574433, type=int)
-    parser.add_argument('-sc', '--sample_count', metavar='INT', help='number of samples to take from the solver', default=100, type=int)
-    parser.add_argument('--solver', help="Solver: 'HIP' (GPU Gibbs / annealing; 'SA' is an alias)", default='HIP', type=str)
-    parser.add_argument('--data_set', help="'mnist', 'breastmnist', 'pneumoniamnist'", default='pneumoniamnist', type=str)
-    parser.add_argument('--num_classes', help='Number of classes in dataset', default=2, type=int)
-    parser.add_argument('--parallelize', help='accepted for compatibility; the GPU path is always batched', default=True, type=_bool)
-    parser.add_argument('--load_path', help='output directory', default="out/", type=str)
-    parser.add_argument('--name', help='Name for run', default="qucun_3492574433", type=str)
-    parser.add_argument('--anneal', help='sweeps per read', default=1000, type=int)
-    parser.add_argument('--data_root', default=None, type=str)
-    parser.add_argument('--max_train', default=None, type=int)
+    # the reference's flags (qbm_main.py:138-216 there: short name, long name, type, default), then the build-side extras
+    CLI = [
+        ("-hn", "--hnodes", int, 2, "hidden units"),
+        ("-lr", "--learning_rate", float, 0.4529451796571889, "learning rate"),
+        ("-r", "--restricted", _bool, False, "no couplings between hidden units"),
+        ("-e", "--epochs", int, 20, "training epochs"),
+        ("-b", "--batch_size", int, 73, "minibatch size"),
+        ("-s", "--seed", int, 3492574433, "seed of the numpy / sampler streams"),
+        ("-sc", "--sample_count", int, 100, "reads per QUBO"),
+        (None, "--solver", str, "HIP", "'HIP' (GPU Gibbs / annealing); 'SA' is accepted as an alias"),
+        (None, "--data_set", str, "pneumoniamnist", "'mnist', 'breastmnist' or 'pneumoniamnist'"),
+        (None, "--num_classes", int, 2, "classes in the dataset"),
+        (None, "--parallelize", _bool, True, "accepted for compatibility: the GPU path is always batched"),
+        (None, "--load_path", str, "out/", "output directory (created if missing)"),
+        (None, "--name", str, "qucun_3492574433", "name of the run"),
+        (None, "--anneal", int, 1000, "sweeps per read"),
+        (None, "--data_root", str, None, "directory holding the reference's src/data tree"),
+        (None, "--max_train", int, None, "use only the first N training images"),
+    ]
+    parser = argparse.ArgumentParser(description="Discriminative QBM with the QUBO sampler on the GPU")
+    for short, long_, typ, default, text in CLI:
+        parser.add_argument(*([short] if short else []), long_, type=typ, default=default, help=text)
     flags = parser.parse_args()
     print("Running with solver", flags.solver)
     os.makedirs(flags.load_path, exist_ok=True)

@@ -19,29 +19,37 @@ from qbm_image_classification_amd.classification_rbm import ClassificationRBM
 
 USE_GPU = True
 
-parser = argparse.ArgumentParser(description='classification_model text classificer')
-parser.add_argument('--lr', type=float, default=0.08714599435919934, help='initial learning rate [default: 0.001]')
-parser.add_argument('--epochs', type=int, default=20, help='number of epochs for train [default: 256]')
-parser.add_argument('--batch-size', type=int, default=7, help='batch size for training [default: 64]')
-parser.add_argument('--early-stop', type=int, default=15, help='iteration numbers to stop without performance increasing')
-parser.add_argument('--visible-units', type=int, default=784, help='Number of dimensions in input')
-parser.add_argument('--hidden-units', type=int, default=9, help='Number of dimensions of the hidden representation')
-parser.add_argument('--no-cuda', action='store_true', default=False, help='disable the gpu')
-parser.add_argument('--cd-k', type=int, default=1, help='The K in the contrastive Divergence Algorithm')
-parser.add_argument('--type', type=str, default='discriminative',
-                    help='The type of training you want to start - discriminative, hybrid and generative')
-parser.add_argument('--sparsity-coeffectient', type=float, default=0.00,
-                    help='The amount that must be subtracted from bias after every update')
-parser.add_argument('--data-folder', type=str, default='data', help='Folder in which the data needs to be stored')
-parser.add_argument('--generative-factor', type=float, default=0.01)
-# build-side extras
-parser.add_argument('--data-root', type=str, default=None, help='directory holding src/data/medmnist/breastmnist.npz')
-parser.add_argument('--seeds', type=int, default=10, help='how many of the 10 reference seeds to run')
-parser.add_argument('--binarise', action='store_true', help='threshold the images at 0.5 ({0,1} visibles)')
-parser.add_argument('--persistent', action='store_true', help='PCD instead of CD-k for generative/hybrid training')
-parser.add_argument('--bars-and-stripes', action='store_true', help='4x4 Bars-and-Stripes instead of BreastMNIST (16 visible units)')
-parser.add_argument('--out-dir', type=str, default='Breast_beta_hyper_RBM')
-parser.add_argument('--host-loader', action='store_true', help="torch DataLoader(shuffle=True) as in the reference instead of the device-resident dataset")
+# The reference's command line (flag, type, default: rbm_main.py:12-30 there), then the build-side extras.
+REFERENCE_FLAGS = [
+    ("--lr", float, 0.08714599435919934, "learning rate"),
+    ("--epochs", int, 20, "training epochs"),
+    ("--batch-size", int, 7, "minibatch size"),
+    ("--early-stop", int, 15, "accepted for compatibility (the reference never reads it either)"),
+    ("--visible-units", int, 784, "input dimension"),
+    ("--hidden-units", int, 9, "hidden units"),
+    ("--cd-k", int, 1, "Gibbs steps of the contrastive-divergence chain"),
+    ("--type", str, "discriminative", "training rule: discriminative, hybrid or generative"),
+    ("--sparsity-coeffectient", float, 0.00, "subtracted from the biases after every update"),
+    ("--data-folder", str, "data", "accepted for compatibility"),
+    ("--generative-factor", float, 0.01, "weight of the CD-k step in hybrid training"),
+]
+EXTRA_FLAGS = [
+    ("--data-root", str, None, "directory holding src/data/medmnist/breastmnist.npz"),
+    ("--seeds", int, 10, "how many of the 10 reference seeds to run"),
+    ("--out-dir", str, "Breast_beta_hyper_RBM", "where acc/auc per epoch are pickled (created if missing)"),
+]
+SWITCHES = [
+    ("--no-cuda", "accepted for compatibility: the HIP path has no CPU fallback"),
+    ("--binarise", "threshold the images at 0.5 ({0,1} visibles, stored bit-packed on the device)"),
+    ("--persistent", "PCD instead of CD-k for generative / hybrid training"),
+    ("--bars-and-stripes", "4x4 Bars-and-Stripes instead of BreastMNIST (16 visible units)"),
+    ("--host-loader", "torch DataLoader(shuffle=True) as in the reference instead of the device-resident dataset"),
+]
+parser = argparse.ArgumentParser(description="ClassificationRBM on the MI355X HIP path (the reference's rbm_main.py command line)")
+for flag, typ, default, text in REFERENCE_FLAGS + EXTRA_FLAGS:
+    parser.add_argument(flag, type=typ, default=default, help=text)
+for flag, text in SWITCHES:
+    parser.add_argument(flag, action="store_true", help=text)
 
 
 def find_breastmnist(root):
