@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QBM_ABI_VERSION 5
+#define QBM_ABI_VERSION 6
 #define QBM_MAX_CLASSES 15 /* class rows + the bias row share one 16-row gradient tile */
 #define QBM_MAX_QUBO_VARS 1024
 
@@ -242,6 +242,13 @@ QBM_API int qbm_kcenter_greedy(const float* embT, int N, int D, const int32_t* s
 QBM_API int qbm_qubo_gibbs(const float* lin, const float* J, int B, int R, int n, int sweeps, float beta0,
                            float beta1, uint64_t seed, uint64_t offset, uint8_t* states, double* mean,
                            void* stream);
+
+/* The same with chain0 = global index of the first chain (image 0, read 0) of this call: Philox rows are chain0 + b*R + r,
+ * so a minibatch sharded over ranks (images of config #5 split over the GPUs) draws exactly the numbers
+ * one process would. */
+QBM_API int qbm_qubo_gibbs_ex(const float* lin, const float* J, int B, int R, int n, int sweeps, float beta0,
+                              float beta1, uint64_t seed, uint64_t offset, uint32_t chain0, uint8_t* states,
+                              double* mean, void* stream);
 
 /* Disc_QBM.get_average_configuration_batch, src/model/faster_dqbm.py:754-848, from the per-image means over
  * reads (float64, images accumulated in order).  labels != NULL = clamped phase (mean[B,H]), NULL = unclamped

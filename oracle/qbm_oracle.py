@@ -323,17 +323,17 @@ def qbm_couplings(W_vh, W_hh, clamped: bool, beta_eff=1.0):
     return J
 
 
-def qubo_gibbs(lin, J, reads, sweeps, beta0=1.0, beta1=1.0, seed=0, offset=0):
-    """-> (states u8 [B,R,n], mean f64 [B,n])"""
+def qubo_gibbs(lin, J, reads, sweeps, beta0=1.0, beta1=1.0, seed=0, offset=0, chain0=0):
+    """-> (states u8 [B,R,n], mean f64 [B,n]); chain0 = global index of the first chain (sharded minibatches)"""
     lin, J = _f32(lin), _f32(J)
     B, n = lin.shape
     states = np.empty((B, reads, n), np.uint8)
     mean = np.empty((B, n), np.float64)
     f = lib().orc_qubo_gibbs
     f.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64, C.c_uint64,
-                  _u8p, _f64p]
+                  C.c_uint32, _u8p, _f64p]
     f.restype = None
-    f(lin, J, B, reads, n, sweeps, beta0, beta1, seed, offset, states, mean)
+    f(lin, J, B, reads, n, sweeps, beta0, beta1, seed, offset, chain0, states, mean)
     return states, mean
 
 

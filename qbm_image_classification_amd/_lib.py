@@ -8,7 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libqbm_hip.so")
 
-QBM_ABI_VERSION = 5
+QBM_ABI_VERSION = 6
 QBM_MAX_CLASSES = 15
 QBM_F32, QBM_U8 = 0, 1
 
@@ -72,6 +72,7 @@ SIGNATURES = {
     "qbm_test_math": [_i, _p, _p, _i, _p],
     "qbm_test_uniform": [_u64, _u64, _u32, _i, _i, _p, _p],
     "qbm_qubo_gibbs": [_p, _p, _i, _i, _i, _i, _f, _f, _u64, _u64, _p, _p, _p],
+    "qbm_qubo_gibbs_ex": [_p, _p, _i, _i, _i, _i, _f, _f, _u64, _u64, _u32, _p, _p, _p],
     "qbm_qbm_batch_stats": [_p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p],
     "qbm_qbm_linear_fields": [_p, _p, _p, _p, _p, C.c_double, _i, _i, _i, C.c_double, _p, _p],
 }

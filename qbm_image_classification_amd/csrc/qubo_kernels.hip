@@ -6,6 +6,7 @@
 // only the linear field depends on the image (:239, :279), so one J[n,n] serves a whole minibatch.
 #include "qbm_device.cuh"
 #include "qbm_host.hpp"
+#include "../../include/qbm_hip.h"
 
 using namespace qbm;
 
@@ -97,10 +98,11 @@ __device__ __forceinline__ void row_of_tile(const JR& jr, int t, int p, int lane
 // One chain (image b, read r) on one wavefront.
 template <int NF, class JR>
 __device__ __forceinline__ void gibbs_chain(const float* __restrict__ lin, const JR& jr, int ch, int R, int n, int sweeps,
-                                            float beta0, float beta1, uint64_t seed, uint64_t offset,
+                                            float beta0, float beta1, uint64_t seed, uint64_t offset, uint32_t chain0,
                                             uint8_t* __restrict__ states, int lane)
 {
     const int b = ch / R;
+    const uint32_t row = chain0 + (uint32_t)ch;   // Philox row: the GLOBAL chain index (sharding-invariant draws)
     float F[NF], thr[NF], jrow[NF];
     bool st[NF];   // this lane's spin of tile t
 
@@ -111,7 +113,7 @@ __device__ __forceinline__ void gibbs_chain(const float* __restrict__ lin, const
         st[t] = false;
         F[t] = 0.f;
         if (i < n) {
-            const f32x4 u = uniform4(seed, offset, (uint32_t)ch, (uint32_t)(i >> 2));
+            const f32x4 u = uniform4(seed, offset, row, (uint32_t)(i >> 2));
             st[t] = u[i & 3] < 0.5f;
             F[t] = lin[(long)b * n + i];
         }
@@ -140,7 +142,7 @@ __device__ __forceinline__ void gibbs_chain(const float* __restrict__ lin, const
         f32x4 ub[NPASS];
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps)
-            ub[ps] = uniform4(seed, offset + (uint64_t)sw, (uint32_t)ch, (uint32_t)(64 * ps + lane));
+            ub[ps] = uniform4(seed, offset + (uint64_t)sw, row, (uint32_t)(64 * ps + lane));
 #pragma unroll
         for (int t = 0; t < NF; ++t) {
             const int i = 64 * t + lane;
@@ -182,7 +184,7 @@ __device__ __forceinline__ void gibbs_chain(const float* __restrict__ lin, const
 template <int NF>
 __global__ __launch_bounds__(256) void k_qubo_gibbs(const float* __restrict__ lin, const float* __restrict__ J,
                                                     int nchains, int R, int n, int sweeps, float beta0,
-                                                    float beta1, uint64_t seed, uint64_t offset,
+                                                    float beta1, uint64_t seed, uint64_t offset, uint32_t chain0,
                                                     uint8_t* __restrict__ states)
 {
     const int lane = threadIdx.x & 63;
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(256) void k_qubo_gibbs(const float* __restrict__ li
     if (ch >= nchains) return;
     JGlobal jr{J, n};
     jr.setup(lane);
-    gibbs_chain<NF>(lin, jr, ch, R, n, sweeps, beta0, beta1, seed, offset, states, lane);
+    gibbs_chain<NF>(lin, jr, ch, R, n, sweeps, beta0, beta1, seed, offset, chain0, states, lane);
 }
 
 // J triangle in LDS: one workgroup of 16 wavefronts per CU, every wavefront walks chains ch = wave id, + total waves, ...
@@ -199,7 +201,7 @@ template <int NF>
 __global__ __launch_bounds__(64 * kGibbsLdsWaves) void k_qubo_gibbs_lds(const float* __restrict__ lin,
                                                                         const float* __restrict__ J, int nchains, int R,
                                                                         int n, int sweeps, float beta0, float beta1,
-                                                                        uint64_t seed, uint64_t offset,
+                                                                        uint64_t seed, uint64_t offset, uint32_t chain0,
                                                                         uint8_t* __restrict__ states)
 {
     extern __shared__ float tri[];
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(64 * kGibbsLdsWaves) void k_qubo_gibbs_lds(const fl
     const int waves = (int)blockDim.x >> 6;
     const int total = gridDim.x * waves;
     for (int ch = blockIdx.x * waves + w; ch < nchains; ch += total)
-        gibbs_chain<NF>(lin, jr, ch, R, n, sweeps, beta0, beta1, seed, offset, states, lane);
+        gibbs_chain<NF>(lin, jr, ch, R, n, sweeps, beta0, beta1, seed, offset, chain0, states, lane);
 }
 
 // mean over reads, float64: exact count / R  (np.average(np_samples, axis=0) on {0,1} samples,
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(256) void k_linear_fields(const double* __restrict_
 
 template <int NF>
 int launch_gibbs(const float* lin, const float* J, int B, int R, int n, int sweeps, float beta0, float beta1,
-                 uint64_t seed, uint64_t offset, uint8_t* states, hipStream_t st)
+                 uint64_t seed, uint64_t offset, uint32_t chain0, uint8_t* states, hipStream_t st)
 {
     const int nch = B * R;
     const size_t tri_bytes = (size_t)n * (n + 1) / 2 * sizeof(float);
@@ -312,12 +314,12 @@ int launch_gibbs(const float* lin, const float* J, int B, int R, int n, int swee
         int waves = (nch + rounds * wgs - 1) / (rounds * wgs);
         waves = waves < 1 ? 1 : waves > kGibbsLdsWaves ? kGibbsLdsWaves : waves;
         hipLaunchKernelGGL((k_qubo_gibbs_lds<NF>), dim3(wgs), dim3(64 * waves), tri_bytes, st, lin, J, nch, R, n, sweeps,
-                           beta0, beta1, seed, offset, states);
+                           beta0, beta1, seed, offset, chain0, states);
         QBM_CHECK_LAUNCH("k_qubo_gibbs_lds");
         return QBM_OK;
     }
     hipLaunchKernelGGL((k_qubo_gibbs<NF>), dim3((nch + 3) / 4), dim3(256), 0, st, lin, J, nch, R, n, sweeps, beta0,
-                       beta1, seed, offset, states);
+                       beta1, seed, offset, chain0, states);
     QBM_CHECK_LAUNCH("k_qubo_gibbs");
     return QBM_OK;
 }
@@ -329,6 +331,12 @@ extern "C" {
 int qbm_qubo_gibbs(const float* lin, const float* J, int B, int R, int n, int sweeps, float beta0, float beta1,
                    uint64_t seed, uint64_t offset, uint8_t* states, double* mean, void* stream)
 {
+    return qbm_qubo_gibbs_ex(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, 0u, states, mean, stream);
+}
+
+int qbm_qubo_gibbs_ex(const float* lin, const float* J, int B, int R, int n, int sweeps, float beta0, float beta1,
+                      uint64_t seed, uint64_t offset, uint32_t chain0, uint8_t* states, double* mean, void* stream)
+{
     if (B < 0 || R < 0) return fail(QBM_ERR_ARG, "qubo_gibbs: negative batch/reads");
     if (B == 0 || R == 0) return QBM_OK;
     if (n <= 0 || n > QBM_MAX_QUBO_VARS) return fail(QBM_ERR_ARG, "qubo_gibbs: n out of range (1..QBM_MAX_QUBO_VARS)");
@@ -339,14 +347,14 @@ int qbm_qubo_gibbs(const float* lin, const float* J, int B, int R, int n, int sw
     const int NF = (n + 63) / 64;
     int rc;
     switch (NF) {
-    case 1: rc = launch_gibbs<1>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, states, st); break;
-    case 2: rc = launch_gibbs<2>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, states, st); break;
-    case 3: rc = launch_gibbs<3>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, states, st); break;
-    case 4: rc = launch_gibbs<4>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, states, st); break;
-    case 5: rc = launch_gibbs<5>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, states, st); break;
-    case 6: rc = launch_gibbs<6>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, states, st); break;
-    case 7: case 8: rc = launch_gibbs<8>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, states, st); break;
-    default: rc = launch_gibbs<16>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, states, st); break;
+    case 1: rc = launch_gibbs<1>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, chain0, states, st); break;
+    case 2: rc = launch_gibbs<2>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, chain0, states, st); break;
+    case 3: rc = launch_gibbs<3>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, chain0, states, st); break;
+    case 4: rc = launch_gibbs<4>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, chain0, states, st); break;
+    case 5: rc = launch_gibbs<5>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, chain0, states, st); break;
+    case 6: rc = launch_gibbs<6>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, chain0, states, st); break;
+    case 7: case 8: rc = launch_gibbs<8>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, chain0, states, st); break;
+    default: rc = launch_gibbs<16>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, chain0, states, st); break;
     }
     if (rc) return rc;
     if (mean) {

@@ -30,7 +30,7 @@ class Disc_QBM:
     def __init__(self, dim_input, num_classes, epochs=2, n_hidden_nodes=4, seed=77, solver="HIP", restricted=False,
                  sample_count=20, anneal_steps=20, beta_eff=1, param_string="", load_path="", speicherort=None,
                  parallelize=False, use_one_hot_encoding=False, use_old_parallization=True, *, beta_range=None,
-                 device="cuda:0", ops=None):
+                 device="cuda:0", ops=None, data_parallel=None):
         if use_one_hot_encoding:
             raise NotImplementedError("one-hot output nodes are not used by any reference driver (qbm_main.py:67)")
         self.epochs = epochs
@@ -70,6 +70,9 @@ class Disc_QBM:
         self._device = device
         self._ops = ops
         self._draw_offset = 0
+        # data parallelism: the images of a minibatch are split over the ranks of the initialised
+        # torch.distributed group; every rank keeps a replica of the parameters
+        self._dp = None if data_parallel is None else bool(data_parallel)
         if load_path != "":
             self.load_savepoint(load_path)
         self.speicherort = speicherort
@@ -147,10 +150,30 @@ class Disc_QBM:
             J[o:, o:] += (whh + whh.T).astype(np.float32)
         return J
 
-    def sample_batch(self, x_batch, y_batch=None):
+    def _dp_group(self):
+        """(rank, world) of the data-parallel group, (0, 1) when not distributed."""
+        import torch.distributed as dist
+
+        on = self._dp if self._dp is not None else (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        if not on:
+            return 0, 1
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("data_parallel=True needs an initialised torch.distributed process group")
+        return dist.get_rank(), dist.get_world_size()
+
+    @staticmethod
+    def _shard(n_rows, rank, world):
+        """Contiguous rows [lo, hi) of rank `rank`: ceil(n/world) rows each, the last ranks may get fewer (or none)."""
+        per = (n_rows + world - 1) // world
+        return min(rank * per, n_rows), min((rank + 1) * per, n_rows)
+
+    def sample_batch(self, x_batch, y_batch=None, rows=None):
         """Both the reference's get_samples_batch (:961-969) and the reduction over reads of
         get_average_configuration_batch (:777-780) for a whole minibatch, on the device:
-        -> (states uint8 [B,R,n], mean float64 [B,n])  (device tensors)."""
+        -> (states uint8 [B,R,n], mean float64 [B,n])  (device tensors).
+        rows=(lo, hi): sample only these images of the minibatch (one rank's shard).  The annealing range still comes
+        from the whole minibatch and the Philox rows are the global chain indices, so the shard's samples are exactly
+        the rows [lo, hi) of the unsharded call."""
         import torch
 
         from .sampler import auto_beta_range
@@ -167,8 +190,14 @@ class Disc_QBM:
             b0, b1 = auto_beta_range(lin.cpu().numpy(), J)
         offset = self._draw_offset
         self._draw_offset += int(self.anneal_steps) + 1
-        return self.ops.gibbs(lin, torch.from_numpy(J), int(self.sample_count), int(self.anneal_steps), b0, b1,
-                              int(self.seed), offset)
+        lo, hi = (0, len(X)) if rows is None else rows
+        n = lin.shape[1]
+        if hi <= lo:
+            dev = lin.device
+            return (torch.empty(0, int(self.sample_count), n, dtype=torch.uint8, device=dev),
+                    torch.empty(0, n, dtype=torch.float64, device=dev))
+        return self.ops.gibbs(lin[lo:hi].contiguous(), torch.from_numpy(J), int(self.sample_count), int(self.anneal_steps),
+                              b0, b1, int(self.seed), offset, True, lo * int(self.sample_count))
 
     @staticmethod
     def _to_dicts(states_row):
@@ -227,6 +256,9 @@ class Disc_QBM:
 
     def train_for_one_iteration(self, x_batch, y_batch, learning_rate, nll=None):
         """src/model/faster_dqbm.py:998-1064 -> (errors_biases_output, avg_batch_nll)"""
+        rank, world = self._dp_group()
+        if world > 1:
+            return self._train_for_one_iteration_dp(x_batch, y_batch, learning_rate, rank, world)
         _, mean_c = self.sample_batch(x_batch, y_batch)      # positive / clamped phase (:1007)
         _, mean_u = self.sample_batch(x_batch)               # negative / unclamped phase (:1011)
         bh_c, bo_c, wvh_c, wvo_c, woo_c, whh_c = self._stats(mean_c, x_batch, y_batch)
@@ -245,6 +277,45 @@ class Disc_QBM:
         if not self.restricted:
             self.weights_hidden_hidden -= learning_rate * ((whh_c - whh_u) / B)   # zeros: W_hh never learns (Q8)
         avg_batch_loss = self.compute_nll(y_batch, mean_u)
+        self.training_history.nll_per_batch.append(avg_batch_loss)
+        return err_bo, avg_batch_loss
+
+    def _train_for_one_iteration_dp(self, x_batch, y_batch, learning_rate, rank, world):
+        """The same update with the images of the minibatch split over the ranks: every rank
+        is handed the SAME minibatch, samples only its rows, and the statistics of both phases (differences of sums
+        over images) plus the NLL sum meet in ONE float64 all-reduce; every replica then applies the same update."""
+        import torch
+        import torch.distributed as dist
+
+        X = np.asarray(x_batch)
+        Y = np.asarray(y_batch).reshape(-1)
+        B = X.shape[0]
+        lo, hi = self._shard(B, rank, world)
+        _, mean_c = self.sample_batch(X, Y, rows=(lo, hi))
+        _, mean_u = self.sample_batch(X, rows=(lo, hi))
+        H, D = self.n_hidden_nodes, self.dim_input
+        flat = np.zeros(H + 1 + (1 + D) * H + D + 1, np.float64)   # [b_h | b_o | W_vh | W_vo | nll sum]
+        if hi > lo:
+            bh_c, bo_c, wvh_c, wvo_c, _, _ = self._stats(mean_c, X[lo:hi], Y[lo:hi])
+            bh_u, bo_u, wvh_u, wvo_u, _, _ = self._stats(mean_u, X[lo:hi], None)
+            flat[:H] = bh_c - bh_u
+            flat[H] = float(np.asarray(bo_c - bo_u).reshape(-1)[0])
+            flat[H + 1:H + 1 + (1 + D) * H] = (wvh_c - wvh_u).reshape(-1)
+            flat[H + 1 + (1 + D) * H:-1] = (wvo_c - wvo_u).reshape(-1)
+            flat[-1] = self.compute_nll(Y[lo:hi], mean_u) * (hi - lo)
+        dev = mean_c.device if dist.get_backend() != "gloo" else torch.device("cpu")
+        t = torch.from_numpy(flat).to(dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        flat = t.cpu().numpy()
+        err_bh, err_bo = flat[:H] / B, np.array([flat[H] / B])
+        err_wvh = flat[H + 1:H + 1 + (1 + D) * H].reshape(1 + D, H) / B
+        err_wvo = flat[H + 1 + (1 + D) * H:-1].reshape(D, 1) / B
+        self.biases_output -= learning_rate * err_bo
+        self.biases_hidden -= learning_rate * err_bh
+        self.weights_all_visible_to_hidden -= learning_rate * err_wvh
+        self.weights_clamped_visible_to_output -= learning_rate * err_wvo
+        # W_oo (empty triu for one output node) and W_hh statistics are identically zero in the reference (Q8)
+        avg_batch_loss = float(flat[-1] / B)
         self.training_history.nll_per_batch.append(avg_batch_loss)
         return err_bo, avg_batch_loss
 

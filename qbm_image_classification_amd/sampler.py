@@ -25,9 +25,9 @@ class HipQuboOps:
             raise _lib.QbmHipError("no ROCm device visible: the HIP path cannot run (there is no CPU fallback)")
         self.device = torch.device(device)
 
-    def gibbs(self, lin, J, reads, sweeps, beta0=1.0, beta1=1.0, seed=0, offset=0, want_mean=True):
+    def gibbs(self, lin, J, reads, sweeps, beta0=1.0, beta1=1.0, seed=0, offset=0, want_mean=True, chain0=0):
         """lin [B,n] f32, J [n,n] f32 symmetric zero-diagonal (device tensors)
-        -> (states u8 [B,R,n], mean f64 [B,n])"""
+        -> (states u8 [B,R,n], mean f64 [B,n]).  chain0: global index of the first chain (sharded minibatches)."""
         lin = lin.to(self.device, torch.float32).contiguous()
         J = J.to(self.device, torch.float32).contiguous()
         B, n = lin.shape
@@ -35,8 +35,8 @@ class HipQuboOps:
             raise _lib.QbmHipError(f"J must be [{n},{n}], got {tuple(J.shape)}")
         states = torch.empty(B, reads, n, dtype=torch.uint8, device=self.device)
         mean = torch.empty(B, n, dtype=torch.float64, device=self.device) if want_mean else None
-        check(self.lib.qbm_qubo_gibbs(ptr(lin), ptr(J), B, reads, n, sweeps, beta0, beta1, seed, offset, ptr(states),
-                                      ptr(mean), current_stream()), "qbm_qubo_gibbs")
+        check(self.lib.qbm_qubo_gibbs_ex(ptr(lin), ptr(J), B, reads, n, sweeps, beta0, beta1, seed, offset, int(chain0),
+                                         ptr(states), ptr(mean), current_stream()), "qbm_qubo_gibbs_ex")
         return states, mean
 
     def linear_fields(self, X, labels, W_vh, W_vo, b_h, b_o, beta_eff=1.0):

@@ -27,12 +27,12 @@ class OracleQuboOps:
     def linear_fields(self, X, labels, W_vh, W_vo, b_h, b_o, beta_eff=1.0):
         return torch.from_numpy(orc.qbm_linear_fields(_np(X, np.float64), labels, W_vh, W_vo, b_h, b_o, beta_eff))
 
-    def gibbs(self, lin, J, reads, sweeps, beta0=1.0, beta1=1.0, seed=0, offset=0, want_mean=True):
+    def gibbs(self, lin, J, reads, sweeps, beta0=1.0, beta1=1.0, seed=0, offset=0, want_mean=True, chain0=0):
         n = lin.shape[1]
         if self.fixed is not None:
             st = self.fixed[n]
             return torch.from_numpy(st), torch.from_numpy(st.astype(np.float64).mean(axis=1))
-        st, mean = orc.qubo_gibbs(_np(lin), _np(J), reads, sweeps, beta0, beta1, seed, offset)
+        st, mean = orc.qubo_gibbs(_np(lin), _np(J), reads, sweeps, beta0, beta1, seed, offset, chain0)
         return torch.from_numpy(st), torch.from_numpy(mean)
 
     def batch_stats(self, X, labels, mean, H):

@@ -87,3 +87,58 @@ def test_two_ranks_match_single_process(method):
         # first step: same parameters on both sides, so the persistent chains must be the same BITS
         both = np.concatenate([ret[0]["outs"][0], ret[1]["outs"][0]])
         assert np.array_equal(both, outs[0])
+
+
+# ---- Disc_QBM (config #5): images of a minibatch split over the ranks ---------------------------------------------
+def _make_qbm(data_parallel):
+    from oracle_backends import OracleQuboOps
+    from qbm_image_classification_amd.disc_qbm import Disc_QBM
+
+    np.random.seed(3)
+    return Disc_QBM(dim_input=12, num_classes=2, n_hidden_nodes=5, seed=7, solver="HIP", sample_count=6, anneal_steps=4,
+                    ops=OracleQuboOps(), data_parallel=data_parallel)
+
+
+def _qbm_data():
+    rs = np.random.RandomState(4)
+    return (rs.random_sample((7, 12)) < 0.4).astype(np.float64), rs.randint(0, 2, 7)   # 7 images: shards of 4 and 3
+
+
+def _qbm_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X, Y = _qbm_data()
+        q = _make_qbm(True)
+        lo, hi = q._shard(len(X), rank, world)
+        states, _ = q.sample_batch(X, Y, rows=(lo, hi))
+        q._draw_offset = 0
+        out = [q.train_for_one_iteration(X, Y, 0.05) for _ in range(3)]
+        ret[rank] = dict(W_vh=q.weights_all_visible_to_hidden.copy(), W_vo=q.weights_clamped_visible_to_output.copy(),
+                         b_h=q.biases_hidden.copy(), b_o=q.biases_output.copy(), out=out, states=states.numpy().copy(), rows=(lo, hi))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_disc_qbm_two_ranks_match_single_process():
+    sys_path = os.path.dirname(os.path.abspath(__file__))
+    os.environ["PYTHONPATH"] = os.pathsep.join([sys_path, os.path.dirname(sys_path), os.environ.get("PYTHONPATH", "")])
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_qbm_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    X, Y = _qbm_data()
+    single = _make_qbm(False)
+    states, _ = single.sample_batch(X, Y)
+    single._draw_offset = 0
+    out = [single.train_for_one_iteration(X, Y, 0.05) for _ in range(3)]
+    assert [ret[r]["rows"] for r in (0, 1)] == [(0, 4), (4, 7)]
+    for r in (0, 1):
+        lo, hi = ret[r]["rows"]
+        assert np.array_equal(ret[r]["states"], states.numpy()[lo:hi])            # a shard's chains are the global chains
+        for k, ref in (("W_vh", single.weights_all_visible_to_hidden), ("W_vo", single.weights_clamped_visible_to_output),
+                       ("b_h", single.biases_hidden), ("b_o", single.biases_output)):
+            assert np.allclose(ret[r][k], ref, rtol=0, atol=1e-12), (r, k)       # float64 sums associated per rank
+        for (e1, n1), (e2, n2) in zip(ret[r]["out"], out):
+            assert np.allclose(e1, e2, atol=1e-12) and abs(n1 - n2) < 1e-6
+    assert np.array_equal(ret[0]["W_vh"], ret[1]["W_vh"]) and np.array_equal(ret[0]["b_h"], ret[1]["b_h"])   # replicas identical

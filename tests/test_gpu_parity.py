@@ -273,6 +273,25 @@ def test_qubo_gibbs_bitwise(oracle):
         assert np.array_equal(mean.cpu().numpy(), mo), "mean over reads (float64: exact count / R)"
 
 
+def test_qubo_gibbs_sharding_invariance(oracle):
+    """Rows [lo, hi) of a minibatch sampled with chain0 = lo * R are exactly the rows [lo, hi) of the whole call (what a
+    data-parallel rank of Disc_QBM does), on both kernels (LDS-resident triangle and J rows from L2)."""
+    from qbm_image_classification_amd.sampler import HipQuboOps
+
+    q = HipQuboOps("cuda:0")
+    rs = np.random.RandomState(8)
+    for (B, R, n, sweeps) in [(73, 20, 257, 5), (9, 3, 40, 6), (6, 40, 300, 3)]:
+        lin = rs.standard_normal((B, n)).astype(np.float32)
+        Ju = np.triu(rs.standard_normal((n, n)).astype(np.float32) * 0.2, 1)
+        J = torch.from_numpy((Ju + Ju.T).astype(np.float32)).cuda()
+        whole, mean = q.gibbs(torch.from_numpy(lin).cuda(), J, R, sweeps, 0.3, 2.0, 5, 9)
+        lo, hi = B // 3, B - 2
+        part, pmean = q.gibbs(torch.from_numpy(lin[lo:hi]).cuda(), J, R, sweeps, 0.3, 2.0, 5, 9, True, lo * R)
+        assert torch.equal(part, whole[lo:hi]) and torch.equal(pmean, mean[lo:hi])
+        so, _ = oracle.qubo_gibbs(lin[lo:hi], J.cpu().numpy(), R, sweeps, 0.3, 2.0, 5, 9, lo * R)
+        assert np.array_equal(part.cpu().numpy(), so)
+
+
 def test_qbm_linear_fields_bitwise(oracle):
     from qbm_image_classification_amd.sampler import HipQuboOps
 
