@@ -16,6 +16,9 @@ import numpy as np
 
 from qbm_image_classification_amd import data_loader, metrics
 from qbm_image_classification_amd.disc_qbm import Disc_QBM
+from qbm_image_classification_amd.launch import finalize_distributed, init_distributed
+
+RANK, WORLD, DEVICE = init_distributed()   # (0, 1, "cuda:0") unless launched by torch.distributed.run
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -63,7 +66,7 @@ def main(seed=19, n_hidden_nodes=10, solver="HIP", sample_count=100, anneal=1000
     dqbm = Disc_QBM(seed=seed, epochs=epochs, n_hidden_nodes=n_hidden_nodes, num_classes=num_classes, solver=solver,
                     sample_count=sample_count, anneal_steps=anneal, beta_eff=beta_eff, restricted=restricted,
                     param_string=param_string, speicherort=save, dim_input=784, parallelize=parallelize,
-                    use_one_hot_encoding=False)
+                    use_one_hot_encoding=False, device=DEVICE)   # under torchrun every minibatch is sharded over the ranks
     print('QBM created')
     print('Training QBM...')
     dqbm.train_model(train_X, train_y, test_X, test_y, batch_size=batch_size, learning_rate=learning_rate)
@@ -71,9 +74,10 @@ def main(seed=19, n_hidden_nodes=10, solver="HIP", sample_count=100, anneal=1000
     print("Predict on test data...")
     predictions = dqbm.predict_batch(test_X)
     acc, f1, precision, recall, auc = metrics.get_metrics(np.asarray(test_y), predictions, ["healthy", "pneumonia"])
-    with open((save or "") + name + "acc_auc.pkl", "wb") as f:
-        pickle.dump((acc, auc), f)
-    metrics.save_history((save or "") + name, dqbm.training_history)
+    if RANK == 0:
+        with open((save or "") + name + "acc_auc.pkl", "wb") as f:
+            pickle.dump((acc, auc), f)
+        metrics.save_history((save or "") + name, dqbm.training_history)
     print("Accuracy: ", acc)
     print("F1 Score: ", f1)
     print("Precision: ", precision)
@@ -112,7 +116,10 @@ if __name__ == '__main__':
     flags = parser.parse_args()
     print("Running with solver", flags.solver)
     os.makedirs(flags.load_path, exist_ok=True)
-    main(epochs=flags.epochs, n_hidden_nodes=flags.hnodes, learning_rate=flags.learning_rate, batch_size=flags.batch_size,
-         solver=flags.solver, restricted=flags.restricted, seed=flags.seed % (2 ** 32), data_set=flags.data_set,
-         num_classes=flags.num_classes, parallelize=flags.parallelize, sample_count=flags.sample_count, save=flags.load_path,
-         name=flags.name, anneal=flags.anneal, data_root=flags.data_root, max_train=flags.max_train)
+    try:
+        main(epochs=flags.epochs, n_hidden_nodes=flags.hnodes, learning_rate=flags.learning_rate, batch_size=flags.batch_size,
+             solver=flags.solver, restricted=flags.restricted, seed=flags.seed % (2 ** 32), data_set=flags.data_set,
+             num_classes=flags.num_classes, parallelize=flags.parallelize, sample_count=flags.sample_count,
+             save=flags.load_path, name=flags.name, anneal=flags.anneal, data_root=flags.data_root, max_train=flags.max_train)
+    finally:
+        finalize_distributed()

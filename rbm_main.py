@@ -16,6 +16,9 @@ import torch
 
 from qbm_image_classification_amd import data_loader
 from qbm_image_classification_amd.classification_rbm import ClassificationRBM
+from qbm_image_classification_amd.launch import finalize_distributed, init_distributed
+
+RANK, WORLD, DEVICE = init_distributed()   # (0, 1, "cuda:0") unless launched by torch.distributed.run
 
 USE_GPU = True
 
@@ -86,7 +89,7 @@ def main(args):
 
         rbm = ClassificationRBM(args.visible_units, args.hidden_units, args.cd_k, num_classes=2, learning_rate=args.lr,
                                 sparse_constant=args.sparsity_coeffectient, use_cuda=not args.no_cuda, seed=seed,
-                                persistent=args.persistent)
+                                persistent=args.persistent, device=DEVICE)
         device = rbm.get_device(False)   # host tensors; the class stages minibatches to the GPU
         train_y_t = torch.from_numpy(np.array(train_y)).to(device).long()
         test_y_t = torch.from_numpy(np.array(test_y)).to(device).long()
@@ -98,16 +101,18 @@ def main(args):
             from qbm_image_classification_amd.device_data import DeviceDataset
 
             train_loader = DeviceDataset(train_X, np.array(train_y), args.batch_size, num_classes=2,
-                                         storage="bits" if args.binarise else "f32", seed=seed, device=str(rbm.device))
+                                         storage="bits" if args.binarise else "f32", seed=seed, device=str(rbm.device),
+                                         rank=RANK, world=WORLD)   # under torchrun: --batch-size rows per rank
         test_loader = torch.utils.data.DataLoader(test_dataset, batch_size=len(training_dataset), shuffle=False)
 
         loss_list, best_model, nll_list = rbm.train_rbm(train_loader=train_loader, test_loader=test_loader,
                                                         epochs=args.epochs, method=args.type,
                                                         generative_factor=args.generative_factor)
-        with open(f'{args.out_dir}/acc_per_epoch{seed}.pkl', 'wb') as f:
-            pickle.dump(rbm.acc_per_epoch_list, f)
-        with open(f'{args.out_dir}/auc_per_epoch{seed}.pkl', 'wb') as f:
-            pickle.dump(rbm.auc_per_epoch_list, f)
+        if RANK == 0:   # the replicas are identical: one of them writes
+            with open(f'{args.out_dir}/acc_per_epoch{seed}.pkl', 'wb') as f:
+                pickle.dump(rbm.acc_per_epoch_list, f)
+            with open(f'{args.out_dir}/auc_per_epoch{seed}.pkl', 'wb') as f:
+                pickle.dump(rbm.auc_per_epoch_list, f)
         results.append((seed, rbm.acc_per_epoch_list[-1], rbm.auc_per_epoch_list[-1]))
     print("seed, final test accuracy, final test AUC")
     for r in results:
@@ -116,4 +121,7 @@ def main(args):
 
 
 if __name__ == '__main__':
-    main(parser.parse_args())
+    try:
+        main(parser.parse_args())
+    finally:
+        finalize_distributed()
