@@ -198,12 +198,15 @@ def main():
         timed = {k: time_kernel(f) for k, (f, _, _) in kernels.items()}
         dom = max(timed, key=lambda k: timed[k] * kernels[k][2])   # most time per CD-1 step
         # HBM bytes per launch of that kernel from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate
-        # rocprofv3 --pmc passes: tools/gpu_pmc_traffic.sh -> profiles/r01_pmc_traffic.json); null if absent
+        # rocprofv3 --pmc passes: tools/gpu_pmc_traffic.sh -> profiles/rNN_pmc_traffic.json); null if absent
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            import glob
+
+            newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]   # latest round's counters
+            with open(newest) as f:
                 traffic = json.load(f)["kernels"][dom.split(" ")[0]]["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, IndexError):
             pass
         fl = kernels[dom][1]
         ach = fl / timed[dom] / 1e12
