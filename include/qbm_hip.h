@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QBM_ABI_VERSION 6
+#define QBM_ABI_VERSION 7
 #define QBM_MAX_CLASSES 15 /* class rows + the bias row share one 16-row gradient tile */
 #define QBM_MAX_QUBO_VARS 1024
 
@@ -115,17 +115,6 @@ QBM_API int qbm_rbm_free_energy(const qbm_rbm_params* P, const float* x, int B, 
 
 /* ---- gradients and update ----------------------------------------------------------------- */
 
-/* Elementwise stage of ClassificationRBM.discriminative_training, src/ClassificationRBM.py:106-126:
- * from pre[B,H], p_y[B,C], labels[B] (int32): pos[B,H] = o_{label}, neg[B,H] = sum_c o_c p_c,
- * onehot[B,C] (may be NULL). */
-QBM_API int qbm_rbm_disc_terms(const qbm_rbm_params* P, const float* pre, const float* p_y, const int32_t* labels,
-                               int B, float* pos, float* neg, float* onehot, void* stream);
-
-/* Class part of the discriminative gradient, src/ClassificationRBM.py:113-115,125,132,136:
- * gU[C,H] (in: onehot^T.pos, from qbm_rbm_two_phase_grad) -= sum_i o_ic p_ic;  gc[C] = sum(onehot - p). */
-QBM_API int qbm_rbm_disc_class_grad(const qbm_rbm_params* P, const float* pre, const float* p_y,
-                                    const int32_t* labels, int B, float* gU, float* gc, void* stream);
-
 /* Two-phase batch gradient (CD-k: SURVEY.md 8.A-7; discriminative: src/ClassificationRBM.py:118-138):
  *   gW = A0^T.P0 - A1^T.P1,  gU = Y0^T.P0 - Y1^T.P1,  gd = colsum(P0) - colsum(P1),
  *   gb = colsum(A0) - colsum(A1),  gc = colsum(Y0) - colsum(Y1)
@@ -170,7 +159,8 @@ QBM_API int qbm_rbm_cd_chain(const qbm_rbm_params* P, const void* v0, int v0_dty
 
 /* chain + gradient (+ update).  fuse_update == 0: the gradients go to G (all five blocks required; the
  * data-parallel path all-reduces them, then calls qbm_rbm_update).  fuse_update != 0: single-GPU path, every
- * parameter block is updated inside the gradient launch (the non-NULL blocks of G are still written). */
+ * parameter block is updated inside the gradient launch (the non-NULL blocks of G are still written).
+ * B == 0 (a rank whose shard of a short last minibatch is empty): the non-NULL blocks of G are zeroed. */
 QBM_API int qbm_rbm_cd_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void* v0, int v0_dtype,
                             const float* y0, int B, int k, uint64_t seed, uint64_t offset, uint32_t row0,
                             uint8_t* chain_v, float* chain_y, const qbm_rbm_cd_workspace* ws, int fuse_update,
@@ -187,7 +177,8 @@ typedef struct {
 
 /* ClassificationRBM.discriminative_training, src/ClassificationRBM.py:101-146 without the host-side
  * loss: p_y[B,C] = p(y|x) before the update (returned third by the reference), neg_free_energy[B,C]
- * optional.  fuse_update as above; apply_update == 0 leaves the parameters untouched (gradients only). */
+ * optional.  fuse_update as above; apply_update == 0 leaves the parameters untouched (gradients only).
+ * B == 0: the non-NULL blocks of G are zeroed, the parameters are left alone. */
 QBM_API int qbm_rbm_disc_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const float* x,
                               const int32_t* labels, int B, float* p_y, float* neg_free_energy,
                               const qbm_rbm_disc_workspace* ws, int apply_update, int fuse_update, float lr,

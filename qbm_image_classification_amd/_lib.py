@@ -8,7 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libqbm_hip.so")
 
-QBM_ABI_VERSION = 6
+QBM_ABI_VERSION = 7
 QBM_MAX_CLASSES = 15
 QBM_F32, QBM_U8 = 0, 1
 
@@ -53,8 +53,6 @@ SIGNATURES = {
     "qbm_rbm_sample_visible": [_PP, _p, _i, _p, _p, _u64, _u64, _u32, _p],
     "qbm_rbm_sample_class": [_PP, _p, _i, _p, _p, _u64, _u64, _u32, _p],
     "qbm_rbm_free_energy": [_PP, _p, _i, _p, _p, _p, _p],
-    "qbm_rbm_disc_terms": [_PP, _p, _p, _p, _i, _p, _p, _p, _p],
-    "qbm_rbm_disc_class_grad": [_PP, _p, _p, _p, _i, _p, _p, _p],
     "qbm_rbm_two_phase_grad": [_i, _i, _i, _i, _p, _i, _p, _p, _p, _i, _p, _p, _GP, _p, _PP, _f, _f, _f, _f, _p],
     "qbm_rbm_sample_visible_class_ex": [_PP, _p, _i, _i, _p, _p, _p, _p, _p, _u64, _u64, _u64, _u32, _p],
     "qbm_f32_to_u8": [_p, _p, C.c_long, _p],

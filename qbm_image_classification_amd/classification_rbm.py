@@ -76,6 +76,7 @@ class ClassificationRBM:
         self._rows_seen = 0       # global row counter (row0 of the next minibatch)
         self._chain_v = None      # persistent chains (PCD)
         self._chain_y = None
+        self._rank_rows = None    # nominal minibatch rows per rank (set by train_rbm from the loader's batch_size)
 
     # ------------------------------------------------------------------------------------------
     def _params(self) -> ParamSet:
@@ -131,11 +132,22 @@ class ClassificationRBM:
                         float(self.sparse_constant), with_gb=with_gb)
 
     def _allreduce_grads(self, local_rows):
+        """ONE collective per step: the flat gradient buffer, whose last element carries the local row count
+        (a rank with an empty shard contributes zeros: the C entry points zero the blocks at B == 0)."""
         import torch.distributed as dist
 
         self._grads.count.fill_(float(local_rows))
-        dist.all_reduce(self._grads.flat, op=dist.ReduceOp.SUM)  # one RCCL collective per step
+        dist.all_reduce(self._grads.flat, op=dist.ReduceOp.SUM)  # RCCL over xGMI
         return float(self._grads.count.item())
+
+    def _rank_row_offset(self, local_rows):
+        """Global index, inside the current global minibatch, of this rank's first row: rank * NOMINAL rows per rank
+        (the loader's batch_size), so that a short last shard does not reuse the Philox rows of the ranks below it."""
+        if not self.data_parallel:
+            return 0
+        import torch.distributed as dist
+
+        return dist.get_rank() * int(self._rank_rows if self._rank_rows else local_rows)
 
     def discriminative_training(self, input_data, class_label, factor=1):
         """src/ClassificationRBM.py:101-146 -> (error, predicted, class_probabilities)"""
@@ -152,6 +164,8 @@ class ClassificationRBM:
             p = self.ops.disc_step(P, self._grads, input_data, class_label, True, not self.keep_grads, lr,
                                    float(factor), float(batch_size), sp)
         labels_dev = torch.as_tensor(class_label).to(self.device).long()
+        if batch_size == 0:   # an empty shard of a short last minibatch (data-parallel ranks only)
+            return torch.zeros((), device=self.device), labels_dev, p
         error = self.loss(p, labels_dev)  # on probabilities, as the reference does (:142)
         _, predicted = torch.max(p, 1)
         return error, predicted, p
@@ -164,20 +178,21 @@ class ClassificationRBM:
         P = self._params()
         labels_dev = torch.as_tensor(class_label).to(self.device).long()
         y0 = torch.nn.functional.one_hot(labels_dev, num_classes=self.num_classes).float()
-        v0 = torch.as_tensor(input_data).to(self.device, torch.float32)
+        v0 = torch.as_tensor(input_data)
+        # uint8 {0,1} minibatches (DeviceDataset with binary storage) stay bytes: the Gibbs kernels read them as such
+        v0 = v0.to(self.device) if v0.dtype == torch.uint8 else v0.to(self.device, torch.float32)
         lr, sp = float(self.learning_rate), float(self.sparse_constant)
-        rank_rows = 0
-        if self.data_parallel:
-            import torch.distributed as dist
-
-            rank_rows = dist.get_rank() * batch_size
-        row0 = (self._rows_seen + rank_rows) & 0xFFFFFFFF
+        row0 = (self._rows_seen + self._rank_row_offset(batch_size)) & 0xFFFFFFFF
         offset = self._next_offset(3 * self.k + 1)
-        if self.persistent and (self._chain_v is None or self._chain_v.shape[0] != batch_size):
-            self._chain_v = self.ops.to_u8(v0)      # chains start at the data (binary states, uint8)
+        if self.persistent and (self._chain_v is None or self._chain_v.shape[0] < batch_size):
+            # chains start at the data.  Chain states are binary (uint8): {0,1} data are taken as they are,
+            # greyscale data are thresholded at 0.5 (data_loader.binarise's rule)
+            self._chain_v = v0.clone() if v0.dtype == torch.uint8 else (v0 > 0.5).to(torch.uint8)
             self._chain_y = y0.clone()
-        cv = self._chain_v if self.persistent else None
-        cy = self._chain_y if self.persistent else None
+        # a short (last) minibatch advances the first `batch_size` chains and leaves the others where they are, so the set
+        # of chains persists over epochs -- and is the same set however the minibatch is sharded over ranks
+        cv = self._chain_v[:batch_size] if self.persistent else None
+        cy = self._chain_y[:batch_size] if self.persistent else None
         self.visible_bias_grad = self._grads.gb
         if self.data_parallel:
             self.ops.cd_step(P, self._grads, v0, y0, self.k, self.seed, offset, row0, cv, cy, False, lr,
@@ -212,6 +227,7 @@ class ClassificationRBM:
         loss_list = []
         nll_list = []
         best_validation_model = None
+        self._rank_rows = getattr(train_loader, 'batch_size', None)   # nominal rows per rank (Philox row offsets)
         for epoch in range(epochs):
             # the running sums live on the device as float64 scalars: the same IEEE double additions, in the same
             # order, as the reference's `epoch_error += batch_error.item()` -- without a host sync per step
@@ -236,6 +252,8 @@ class ClassificationRBM:
                     raise NotImplementedError(method)
 
                 epoch_error_t += batch_error.detach().double()
+                if batch.size(0) == 0:   # empty shard of a short last minibatch (data-parallel ranks only)
+                    continue
                 # NLL of the batch (:188-191)
                 log_probs = torch.log(class_probs + 1e-8)
                 nll = -log_probs[torch.arange(batch.size(0), device=self.device), labels.long()]
@@ -283,9 +301,7 @@ class ClassificationRBM:
         all_labels = []
         for batch, labels in test_loader:
             batch = batch.view(len(batch), self.num_visible)
-            predicted_probabilities = self.sample_class_given_x(batch)
-            _, predicted = torch.max(predicted_probabilities, 1)
-            predicted = predicted.cpu()
+            predicted = self._predict_rows(batch).cpu()
             all_preds.extend(predicted.numpy())
             all_labels.extend(labels.cpu().numpy())
             total += labels.size(0)
@@ -295,6 +311,29 @@ class ClassificationRBM:
         auc_score = roc_auc_score(all_labels, all_preds)
         print('AUC Score: %.4f' % auc_score)
         return accuracy, auc_score
+
+    def _predict_rows(self, batch):
+        """argmax_y p(y|x) for every row.  Data parallel: every rank is handed the same evaluation
+        batch, classifies only its contiguous share of the rows, and one all-reduce of the [rows] prediction vector
+        (zeros outside the own share) gives every rank all predictions -- from which (correct, total) and the AUC
+        follow exactly as in the single-process loop."""
+        n = batch.size(0)
+        if not self.data_parallel or n == 0:
+            return torch.max(self.sample_class_given_x(batch), 1)[1]
+        import torch.distributed as dist
+
+        rank, world = dist.get_rank(), dist.get_world_size()
+        per = (n + world - 1) // world
+        lo, hi = min(rank * per, n), min((rank + 1) * per, n)
+        pred = torch.zeros(n, dtype=torch.int64, device=self.device)
+        if hi > lo:
+            pred[lo:hi] = torch.max(self.sample_class_given_x(batch[lo:hi]), 1)[1]
+        if dist.get_backend() == "gloo":   # CPU test harness: the collective runs on host memory
+            host = pred.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            return host.to(self.device)
+        dist.all_reduce(pred, op=dist.ReduceOp.SUM)
+        return pred
 
     def get_num_params(self):
         """src/ClassificationRBM.py:297-307"""

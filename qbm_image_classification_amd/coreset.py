@@ -17,12 +17,11 @@ from ._lib import check, current_stream, ptr
 
 
 def euclidean_dist(x, y):
-    """The reference's metric (src/coreset.py:6-13), kept for callers that import it; torch, any device."""
-    m, n = x.size(0), y.size(0)
-    xx = torch.pow(x, 2).sum(1, keepdim=True).expand(m, n)
-    yy = torch.pow(y, 2).sum(1, keepdim=True).expand(n, m).t()
-    dist = xx + yy - 2.0 * (x @ y.t())
-    return dist.clamp(min=1e-12).sqrt()
+    """Pairwise Euclidean distances [m, n] between the rows of x [m, d] and y [n, d], floored at 1e-6 (= sqrt(1e-12)),
+    for callers that import the reference's helper of this name (src/coreset.py:6-13); torch, any device.  The picks
+    themselves never call it: they run in csrc/coreset_kernels.hip."""
+    sq = (x * x).sum(dim=1)[:, None] + (y * y).sum(dim=1)[None, :] - 2.0 * torch.mm(x, y.transpose(0, 1))
+    return torch.sqrt(torch.clamp(sq, min=1e-12))
 
 
 def kcenter_picks(emb, seeds, n_picks, device="cuda:0"):

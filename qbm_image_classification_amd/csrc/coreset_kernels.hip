@@ -8,7 +8,7 @@
 //   dot     = chain t = fmaf(x_pk, x_jk, t), k ascending            (:11 addmm_)
 //   d(p,j)  = sqrt(max((sq[p] + sq[j]) - 2*dot, 1e-12))             (:10-12), sqrt correctly rounded
 // The embedding matrix is read transposed ([D,N]: lane j streams column j, coalesced).
-#include "qbm_device.cuh"
+#include "qbm_device.hip.h"
 #include "qbm_host.hpp"
 #include "../../include/qbm_hip.h"
 

@@ -2,7 +2,7 @@
 // the training set lives in HBM (fp32 greyscale, uint8 {0,1}, or bit-packed 98 B per 28x28 image), the epoch
 // permutation is made on the device and a minibatch is one gather launch -- no host copy per step.
 // Byte / integer work only: results are exact, the oracle restates them in numpy.
-#include "qbm_device.cuh"
+#include "qbm_device.hip.h"
 #include "qbm_host.hpp"
 #include "../../include/qbm_hip.h"
 

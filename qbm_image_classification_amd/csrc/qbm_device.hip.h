@@ -1,4 +1,4 @@
-// qbm_device.cuh -- device-side building blocks for the gfx950 Gibbs / CD kernels.
+// qbm_device.hip.h -- device-side building blocks for the gfx950 Gibbs / CD kernels.
 //
 // Numerical contract (DESIGN.md "Numerical contract"): IEEE binary32, round-to-nearest-even,
 // compiled with -ffp-contract=off; an FMA happens only where __builtin_fmaf is written or an

@@ -4,7 +4,7 @@
 //     E(s) = sum_i lin_i s_i + sum_{i<j} J_ij s_i s_j,   P(s) ~ exp(-beta E).
 // The quadratic part J of Disc_QBM's QUBO is image-independent (faster_dqbm.py:242-243, 256-271);
 // only the linear field depends on the image (:239, :279), so one J[n,n] serves a whole minibatch.
-#include "qbm_device.cuh"
+#include "qbm_device.hip.h"
 #include "qbm_host.hpp"
 #include "../../include/qbm_hip.h"
 

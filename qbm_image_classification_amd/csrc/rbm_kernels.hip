@@ -1,7 +1,7 @@
 // rbm_kernels.hip -- ClassificationRBM hot path on gfx950 (MI355X): block-Gibbs conditionals,
 // free-energy evaluation, two-phase (CD-k / discriminative) gradient, parameter update.
 // Reference semantics: src/ClassificationRBM.py (file:line cited per kernel), SURVEY.md 8.A.
-#include "strip_mma.cuh"
+#include "strip_mma.hip.h"
 #include "qbm_host.hpp"
 
 using namespace qbm;
@@ -352,8 +352,9 @@ __global__ __launch_bounds__(256) void k_visible(VisibleArgs a)
 // ---------------------------------------------------------------------------------------------
 // One workgroup per row, one wave per class (blockDim = 64 C): wave c does the wave tree [T] over j for class c,
 // the -F values meet in LDS, thread (c, d) forms exp(F_c - F_d) and thread c adds them up in d order -> p(y|x).
-// With `pos` set, the workgroup goes on to the elementwise stage of discriminative_training for its row
-// (k_disc_terms below, same operation order) while p is still in LDS.
+// With `pos` set, the workgroup goes on to the elementwise stage of discriminative_training for its row while p is
+// still in LDS (src/ClassificationRBM.py:106-107, :113-115, :124-126):  o_c = sigma(pre + U_c);  pos = o_{label};
+// neg = sum_c o_c * p_c (mul, then add, classes ascending).
 template <int CM>
 __global__ __launch_bounds__(64 * CM) void k_free_energy(const float* __restrict__ pre, const float* __restrict__ U,
                                                          const float* __restrict__ cb, float* __restrict__ negF,
@@ -408,32 +409,6 @@ __global__ __launch_bounds__(64 * CM) void k_free_energy(const float* __restrict
         pos[(long)i * H + j] = ps;
         neg[(long)i * H + j] = ng;
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// A-5  discriminative_training, elementwise stage (src/ClassificationRBM.py:106-107, :113-115,
-// :124-126):  o_c = sigma(pre + U_c);  pos = o_{label};  neg = sum_c o_c * p_c (mul, then add).
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_disc_terms(const float* __restrict__ pre, const float* __restrict__ U,
-                                                    const float* __restrict__ p, const int* __restrict__ labels,
-                                                    float* __restrict__ pos, float* __restrict__ neg,
-                                                    float* __restrict__ onehot, int B, int H, int C)
-{
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)B * H) return;
-    const int i = (int)(idx / H), j = (int)(idx % H);
-    const float pr = pre[idx];
-    const int lab = labels[i];
-    if (j == 0 && onehot)
-        for (int c = 0; c < C; ++c) onehot[(long)i * C + c] = (c == lab) ? 1.f : 0.f;
-    float ng = 0.f, ps = 0.f;
-    for (int c = 0; c < C; ++c) {
-        const float o = det_sigmoid(pr + U[(long)c * H + j]);
-        if (c == lab) ps = o;
-        ng = ng + o * p[(long)i * C + c];
-    }
-    pos[idx] = ps;
-    neg[idx] = ng;
 }
 
 // theta += ((factor * g) * lr) / bs, then - sparse for the biases (src/ClassificationRBM.py:88-99)
@@ -762,6 +737,21 @@ int check_params(const qbm_rbm_params* P)
 
 int check_dtype(int dt) { return (dt == QBM_F32 || dt == QBM_U8) ? QBM_OK : fail(QBM_ERR_ARG, "dtype must be QBM_F32 or QBM_U8"); }
 
+// A call with no rows contributes nothing: its gradient blocks are zeroed so that a data-parallel rank whose
+// shard of a short last minibatch is empty adds zeros to the all-reduce (not the previous step's gradients).
+int zero_grads(const qbm_rbm_params* P, const qbm_rbm_grads* G, hipStream_t st)
+{
+    if (!G) return QBM_OK;
+    const struct { float* p; size_t n; } blk[5] = {{G->gW, (size_t)P->V * P->H}, {G->gb, (size_t)P->V}, {G->gd, (size_t)P->H},
+                                                    {G->gU, (size_t)P->C * P->H}, {G->gc, (size_t)P->C}};
+    for (const auto& b : blk)
+        if (b.p) {
+            hipError_t e = hipMemsetAsync(b.p, 0, b.n * sizeof(float), st);
+            if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(gradient block)");
+        }
+    return QBM_OK;
+}
+
 inline bool small2g(long elems, int esz) { return elems * esz < (1L << 31); }
 
 template <class TA>
@@ -976,33 +966,6 @@ int qbm_rbm_free_energy(const qbm_rbm_params* P, const float* x, int B, float* p
     return QBM_OK;
 }
 
-int qbm_rbm_disc_terms(const qbm_rbm_params* P, const float* pre, const float* p_y, const int32_t* labels, int B,
-                       float* pos, float* neg, float* onehot, void* stream)
-{
-    if (int rc = check_params(P)) return rc;
-    if (B <= 0) return B == 0 ? QBM_OK : fail(QBM_ERR_ARG, "B < 0");
-    if (!pre || !p_y || !labels || !pos || !neg) return fail(QBM_ERR_ARG, "disc_terms: null buffer");
-    const long n = (long)B * P->H;
-    hipLaunchKernelGGL(k_disc_terms, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pre, P->U,
-                       p_y, labels, pos, neg, onehot, B, P->H, P->C);
-    QBM_CHECK_LAUNCH("k_disc_terms");
-    return QBM_OK;
-}
-
-int qbm_rbm_disc_class_grad(const qbm_rbm_params* P, const float* pre, const float* p_y, const int32_t* labels,
-                            int B, float* gU, float* gc, void* stream)
-{
-    if (int rc = check_params(P)) return rc;
-    if (B <= 0) return B == 0 ? QBM_OK : fail(QBM_ERR_ARG, "B < 0");
-    if (!pre || !p_y || !labels || !gU) return fail(QBM_ERR_ARG, "disc_class_grad: null buffer");
-    const int n = P->C * ((P->H + 15) / 16);
-    hipLaunchKernelGGL(k_disc_class_grad, dim3(n), dim3(256), 0, (hipStream_t)stream, pre, P->U, p_y, labels,
-                       (float*)nullptr, gU, gc, (float*)nullptr, (float*)nullptr, StepScale{0.f, 0.f, 1.f, 0.f}, B, P->H,
-                       P->C, P->V);
-    QBM_CHECK_LAUNCH("k_disc_class_grad");
-    return QBM_OK;
-}
-
 int qbm_rbm_two_phase_grad(int V, int H, int C, int B, const void* A0, int a0_dtype, const float* Y0, const float* P0,
                            const void* A1, int a1_dtype, const float* Y1, const float* P1, const qbm_rbm_grads* G,
                            float* W_fused, const qbm_rbm_params* aux_fused, float lr, float factor, float batch_size,
@@ -1089,7 +1052,7 @@ int qbm_rbm_cd_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void*
     if (!fuse_update && (!G->gW || !G->gb || !G->gd || !G->gU || !G->gc))
         return fail(QBM_ERR_ARG, "cd_step: all gradient blocks are required without fuse_update");
     if (int rc = qbm_rbm_cd_chain(P, v0, v0_dtype, y0, B, k, seed, offset, row0, chain_v, chain_y, ws, stream)) return rc;
-    if (B == 0) return QBM_OK;
+    if (B == 0) return zero_grads(P, G, (hipStream_t)stream);
     if (!(batch_size > 0.f)) return fail(QBM_ERR_ARG, "cd_step: batch_size must be positive");
     qbm_rbm_grads g = *G;
     if (fuse_update) g.gW = nullptr;  // the whole update happens inside the gradient launch
@@ -1103,7 +1066,8 @@ int qbm_rbm_disc_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const flo
                       int fuse_update, float lr, float factor, float batch_size, float sparse_constant, void* stream)
 {
     if (int rc = check_params(P)) return rc;
-    if (B <= 0) return B == 0 ? QBM_OK : fail(QBM_ERR_ARG, "B < 0");
+    if (B < 0) return fail(QBM_ERR_ARG, "B < 0");
+    if (B == 0) return zero_grads(P, G, (hipStream_t)stream);
     if (!G || !G->gd || !G->gU || !G->gc) return fail(QBM_ERR_ARG, "disc_step: gd, gU, gc are required");
     if (!x || !labels || !p_y || !ws || !ws->pre || !ws->pos || !ws->neg || !ws->onehot || !ws->cls_neg)
         return fail(QBM_ERR_ARG, "disc_step: null buffer");

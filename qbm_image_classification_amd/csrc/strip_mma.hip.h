@@ -1,4 +1,4 @@
-// strip_mma.cuh -- the K-quartered strip contraction every dense product of the path runs on.
+// strip_mma.hip.h -- the K-quartered strip contraction every dense product of the path runs on.
 //
 // One workgroup = 4 wavefronts = the 4 SIMDs of one CU.  It owns a (16*MT) x (16*NT) strip of the
 // output.  Wave q contracts K-quarter q ([Q] of the numerical contract) with
@@ -27,7 +27,7 @@
 // A "piece" is 16 consecutive k (4 MFMA k-steps).  Out-of-range k / rows are staged as zeros from a
 // 16-byte zero page, so the MFMA loop needs no masks (fmaf(0, b, acc) == acc).
 #pragma once
-#include "qbm_device.cuh"
+#include "qbm_device.hip.h"
 #include <type_traits>
 
 // diagnostic builds (tools/microbench) define QBM_STAMP(i) to record s_memtime at phase boundaries;

@@ -20,20 +20,18 @@ class History:
 
 
 def get_metrics(y_true, y_predict, class_titles):
-    from sklearn.metrics import accuracy_score, f1_score, precision_score, recall_score, roc_auc_score
+    """-> (accuracy, f1, precision, recall, auc), the tuple order Disc_QBM.train_model unpacks
+    (reference contract: src/metrics.py:190-202).  Two classes: positive-class scores and the ROC AUC of the HARD
+    predictions; more classes: macro averages and auc = 0."""
+    from sklearn import metrics as skm
 
-    acc = accuracy_score(y_true, y_predict)
-    if len(class_titles) == 2:
-        f1 = f1_score(y_true, y_predict, average='binary')
-        precision = precision_score(y_true, y_predict, average='binary', zero_division=0)
-        recall = recall_score(y_true, y_predict, average='binary')
-        auc = roc_auc_score(y_true, y_predict)   # on hard predictions, like the reference
-    else:
-        f1 = f1_score(y_true, y_predict, average='macro')
-        precision = precision_score(y_true, y_predict, average='macro', zero_division=0)
-        recall = recall_score(y_true, y_predict, average='macro')
-        auc = 0
-    return acc, f1, precision, recall, auc
+    binary = len(class_titles) == 2
+    avg = "binary" if binary else "macro"
+    scores = {fn.__name__: fn(y_true, y_predict, average=avg, **kw)
+              for fn, kw in ((skm.f1_score, {}), (skm.precision_score, {"zero_division": 0}), (skm.recall_score, {}))}
+    auc = skm.roc_auc_score(y_true, y_predict) if binary else 0
+    return (skm.accuracy_score(y_true, y_predict), scores["f1_score"], scores["precision_score"],
+            scores["recall_score"], auc)
 
 
 def save_history(file_path_and_name, history: History):

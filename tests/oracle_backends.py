@@ -90,7 +90,17 @@ class OracleRbmOps:
         for t, a in zip((P.W, P.b, P.d, P.U, P.c), (W, b, d, U, c)):
             t.copy_(torch.from_numpy(a))
 
+    @staticmethod
+    def _zero(G, with_gb=True):
+        # the C ABI's contract for a call with no rows (include/qbm_hip.h, qbm_rbm_cd_step / qbm_rbm_disc_step): the
+        # gradient blocks handed in are zeroed, the parameters are left alone
+        for t in (G.gW, G.gd, G.gU, G.gc) + ((G.gb,) if with_gb else ()):
+            t.zero_()
+
     def disc_step(self, P, G, x, labels, apply_update, fuse, lr, factor, batch_size, sparse):
+        if len(x) == 0:
+            self._zero(G, with_gb=False)
+            return torch.empty(0, P.C)
         W, b, d, U, c = self._P(P)
         gW, gd, gU, gc, p, _ = orc.rbm_disc_grad(_np(x), _np(labels, np.int32), W, d, U, c)
         self._store(G, gW, None, gd, gU, gc)
@@ -100,6 +110,9 @@ class OracleRbmOps:
 
     def cd_step(self, P, G, v0, y0, k, seed, offset, row0, chain_v, chain_y, fuse, lr, factor, batch_size, sparse,
                 ws=None):
+        if len(v0) == 0:
+            self._zero(G)
+            return tuple(torch.empty(0, n) for n in (P.H, P.H, P.V, P.C, P.H))
         W, b, d, U, c = self._P(P)
         cv = None if chain_v is None else _np(chain_v)
         cy = None if chain_y is None else _np(chain_y)

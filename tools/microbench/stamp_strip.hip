@@ -13,7 +13,7 @@ __device__ unsigned long long g_stamps[1024 * 4 * 8];
     } while (0)
 __device__ int g_diag;
 #define QBM_DIAG_MODE g_diag
-#include "strip_mma.cuh"
+#include "strip_mma.hip.h"
 using namespace qbm;
 
 template <class TA, int MT, int NT, bool BK4>
