@@ -98,3 +98,38 @@ def test_checkpoint_roundtrip(tmp_path):
                   ops=OracleQuboOps())
     assert np.array_equal(q2.weights_all_visible_to_hidden, q.weights_all_visible_to_hidden)
     assert np.array_equal(q2.weights_hidden_hidden, q.weights_hidden_hidden)
+
+
+def _check_couplings(q, Q_clamped, Q_unclamped):
+    """`_couplings` feeds every training launch: J = off-diagonal of the reference's upper-triangular QUBO, symmetrised,
+    in fp32 (src/model/faster_dqbm.py:242-243, :256-271)."""
+    for clamped, Qs in ((True, Q_clamped), (False, Q_unclamped)):
+        if Qs is None:
+            continue
+        J = q._couplings(clamped)
+        n = Qs.shape[-1]
+        assert J.shape == (n, n) and J.dtype == np.float32
+        assert np.array_equal(J, J.T) and not np.diag(J).any()
+        for Q in Qs:                                   # the quadratic part does not depend on the image
+            off = Q - np.diag(np.diag(Q))
+            assert not np.tril(off).any()              # the reference's Q is upper triangular
+            assert np.array_equal(np.triu(J, 1), off.astype(np.float32))
+
+
+def test_couplings_match_reference_qubo_offdiagonals():
+    g = golden("qbm_small.npz")
+    _check_couplings(make(g), g["Q_clamped"], g["Q_unclamped"])            # unrestricted: W_hh and the label row
+    g2 = golden("qbm_784.npz")
+    from qbm_image_classification_amd.disc_qbm import Disc_QBM
+
+    np.random.seed(99)
+    q2 = Disc_QBM(dim_input=784, num_classes=2, n_hidden_nodes=16, seed=int(g2["seed"]), solver="HIP", restricted=True,
+                  sample_count=10, anneal_steps=10, beta_eff=1.0, ops=OracleQuboOps())
+    _check_couplings(q2, None, g2["Q_unclamped"])                          # restricted 784-input model: label row only
+    assert not q2._couplings(True).any()                                   # clamped + restricted: no couplings at all
+    # beta_eff scales the couplings like the rest of Q (:245, :283)
+    q3 = make(g)
+    q3.beta_eff = 2.0
+    off = g["Q_unclamped"][0] - np.diag(np.diag(g["Q_unclamped"][0]))
+    want = (off + off.T) * float(g["beta_eff"]) / 2.0
+    assert np.allclose(q3._couplings(False), want, rtol=1e-7, atol=0)

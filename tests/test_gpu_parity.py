@@ -204,6 +204,113 @@ def test_cd_step_bitwise(ops, oracle, V, H, C, B, k, pcd):
                 assert_bitwise(got, want, f"{nm} after fused update")
 
 
+def test_config3_pcd10_full_size_carried_state(ops, oracle):
+    """BASELINE.json configs[2] exactly: 784v x 512h, C = 10, CD-10 with persistent chains, batch 256.  Three consecutive
+    steps with the chains AND the parameters carried from step to step; every sampled bit, every probability and every
+    parameter is compared with the oracle after every step."""
+    from qbm_image_classification_amd.rbm_ops import GradSet
+
+    V, H, C, B, k = 784, 512, 10, 256, 10
+    W, b, d, U, c = synth_params(V, H, C, 33)
+    P = P_of(ops, W, b, d, U, c)
+    G = GradSet(V, H, C, ops.device)
+    ws = ops.cd_workspace(P, B)
+    v_init, _, _, lab_init, y_init = synth_inputs(B, V, H, C, 50)
+    cv_o, cy_o = v_init.copy(), y_init.copy()                      # oracle-side chains (updated in place)
+    cv, cy = dev(ops, v_init.astype(np.uint8)), dev(ops, y_init)
+    seed, lr, sparse = 4242, 0.05, 0.0001
+    for step in range(3):
+        v_bin, _, _, _, y1h = synth_inputs(B, V, H, C, 60 + step)
+        off, row0 = (3 * k + 1) * step, 256 * step
+        ops.cd_step(P, G, dev(ops, v_bin.astype(np.uint8)), dev(ops, y1h), k, seed, off, row0, cv, cy, True, lr, 1.0,
+                    float(B), sparse, ws)
+        ph0, vk, yk, phk = oracle.rbm_cd_chain(v_bin, y1h, W, b, d, U, c, k, seed, off, row0, cv_o, cy_o)
+        g = oracle.rbm_two_phase_grad(v_bin, y1h, ph0, vk, yk, phk)
+        oracle.rbm_update(W, b, d, U, c, *g, lr, 1.0, float(B), sparse)
+        assert_bitwise(ws[0], ph0, f"p(h0), step {step}")
+        assert np.array_equal(ws[2].cpu().numpy(), vk.astype(np.uint8)), f"v_k, step {step}"
+        assert_bitwise(ws[3], yk, f"y_k, step {step}")
+        assert_bitwise(ws[4], phk, f"p(h_k), step {step}")
+        assert np.array_equal(cv.cpu().numpy(), cv_o.astype(np.uint8)), f"persistent v, step {step}"
+        assert_bitwise(cy, cy_o, f"persistent y, step {step}")
+        for got, want, nm in ((P.W, W, "W"), (P.b, b, "b"), (P.d, d, "d"), (P.U, U, "U"), (P.c, c, "c")):
+            assert_bitwise(got, want, f"{nm} after step {step}")
+        for got, want, nm in ((G.gb, g[1], "gb"), (G.gd, g[2], "gd"), (G.gU, g[3], "gU"), (G.gc, g[4], "gc")):
+            assert_bitwise(got, want, f"{nm}, step {step}")
+    assert not np.array_equal(cv_o, v_init)                         # the chains moved
+
+
+@pytest.mark.parametrize("V,H,C,B,k", [(784, 512, 10, 256, 1), (784, 128, 2, 128, 2), (13, 9, 3, 5, 1)])
+def test_data_parallel_code_path_on_device(ops, oracle, V, H, C, B, k):
+    """What one rank of the data-parallel step runs (BASELINE.json configs[3]): cd_step(fuse=0) materialises ALL five
+    gradient blocks, (the all-reduce: identity on one rank), then qbm_rbm_update applies them -- bit-exact against the
+    oracle's update.  Then the two-rank arithmetic: half-batches at row0 = 0 / B/2, gradients summed (what the all-reduce
+    does), one update with the global batch size -- chains bit-identical to the whole batch, parameters within fp32
+    rounding of the single-batch result (the batch sum is associated per rank)."""
+    from qbm_image_classification_amd.rbm_ops import GradSet
+
+    W, b, d, U, c = synth_params(V, H, C, 700 + V + H)
+    v_bin, _, _, _, y1h = synth_inputs(B, V, H, C, 12)
+    seed, off, row0, lr, sparse = 7, 40, 2048, 0.05, 0.001
+    P = P_of(ops, W, b, d, U, c)
+    G = GradSet(V, H, C, ops.device)
+    v8 = dev(ops, v_bin.astype(np.uint8))
+    ws = ops.cd_step(P, G, v8, dev(ops, y1h), k, seed, off, row0, None, None, False, lr, 1.0, float(B), sparse)
+    for got, want, nm in ((P.W, W, "W"), (P.b, b, "b"), (P.d, d, "d"), (P.U, U, "U"), (P.c, c, "c")):
+        assert_bitwise(got, want, f"{nm} untouched by cd_step(fuse=0)")
+    ph0, vk, yk, phk = oracle.rbm_cd_chain(v_bin, y1h, W, b, d, U, c, k, seed, off, row0)
+    g = oracle.rbm_two_phase_grad(v_bin, y1h, ph0, vk, yk, phk)
+    for got, want, nm in zip((G.gW, G.gb, G.gd, G.gU, G.gc), g, ("gW", "gb", "gd", "gU", "gc")):
+        assert_bitwise(got, want, nm)
+    ops.update(P, G, lr, 1.0, float(B), sparse)                     # with_gb=True: all five blocks
+    Wn, bn, dn, Un, cn = (a.copy() for a in (W, b, d, U, c))
+    oracle.rbm_update(Wn, bn, dn, Un, cn, *g, lr, 1.0, float(B), sparse)
+    for got, want, nm in ((P.W, Wn, "W"), (P.b, bn, "b"), (P.d, dn, "d"), (P.U, Un, "U"), (P.c, cn, "c")):
+        assert_bitwise(got, want, f"{nm} after qbm_rbm_update")
+    if B < 2:
+        return
+    # two "ranks"
+    half = B // 2
+    P2 = P_of(ops, W, b, d, U, c)
+    Gs = [GradSet(V, H, C, ops.device) for _ in range(2)]
+    vks = []
+    for r, (lo, hi) in enumerate(((0, half), (half, B))):
+        w2 = ops.cd_step(P2, Gs[r], v8[lo:hi].contiguous(), dev(ops, y1h[lo:hi]), k, seed, off, row0 + lo, None, None, False,
+                         lr, 1.0, float(hi - lo), sparse)
+        vks.append(w2[2].clone())
+    assert torch.equal(torch.cat(vks), ws[2])                        # sharded chains == the whole batch's chains, bit for bit
+    Gs[0].flat += Gs[1].flat                                          # the all-reduce
+    ops.update(P2, Gs[0], lr, 1.0, float(B), sparse)
+    for got, want, nm in ((P2.W, Wn, "W"), (P2.b, bn, "b"), (P2.d, dn, "d"), (P2.U, Un, "U"), (P2.c, cn, "c")):
+        err = np.max(np.abs(got.cpu().numpy() - want))
+        assert err <= 2e-6, (nm, err)
+
+
+def test_empty_shard_zeroes_gradients(ops):
+    """B == 0 (a data-parallel rank whose shard of a short last minibatch is empty): the gradient blocks are zeroed, so the
+    all-reduce adds nothing from this rank, and the parameters stay as they are."""
+    from qbm_image_classification_amd.rbm_ops import GradSet
+
+    V, H, C = 784, 128, 2
+    W, b, d, U, c = synth_params(V, H, C, 3)
+    P = P_of(ops, W, b, d, U, c)
+    G = GradSet(V, H, C, ops.device)
+    e = lambda n, dt=torch.float32: torch.empty(0, n, dtype=dt, device=ops.device)
+    for call in ("cd", "disc"):
+        G.flat.fill_(3.0)
+        if call == "cd":
+            ops.cd_step(P, G, e(V, torch.uint8), e(C), 1, 1, 0, 0, None, None, False, 0.05, 1.0, 1.0, 0.0)
+            assert not G.flat[:-1].any()
+        else:
+            p = ops.disc_step(P, G, e(V), torch.empty(0, dtype=torch.int32, device=ops.device), False, False, 0.05, 1.0,
+                              1.0, 0.0)
+            assert p.shape == (0, C)
+            assert not G.gW.any() and not G.gd.any() and not G.gU.any() and not G.gc.any()
+            assert (G.gb == 3.0).all()                                # the discriminative step never owns gb (:138)
+        assert float(G.count) == 3.0                                  # the row-count slot belongs to the caller
+    assert_bitwise(P.W, W, "W untouched")
+
+
 def test_sharding_invariance_full_size(ops):
     """Size-independent property at the benchmark shape: sampling rows [0,256) in one call equals two
     calls on the halves with row0 = 0 / 128 (what two data-parallel ranks would do), bit for bit."""
