@@ -37,3 +37,36 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-30))
+
+
+class ReplayLoader:
+    """Minibatches in a RECORDED sample order (one row of `order` per epoch), e.g. the order in which the reference's
+    DataLoader(shuffle=True) visited the training set in a golden run (tools/make_golden_runs.py)."""
+
+    def __init__(self, X, y, order, batch_size):
+        import torch
+
+        self.X, self.y = torch.as_tensor(X), torch.as_tensor(y).long()
+        self.order, self.batch_size, self.epoch = np.asarray(order, dtype=np.int64), int(batch_size), 0
+
+    def __len__(self):
+        return (self.order.shape[1] + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        import torch
+
+        idx = torch.from_numpy(self.order[self.epoch])
+        self.epoch += 1
+        for lo in range(0, len(idx), self.batch_size):
+            sel = idx[lo:lo + self.batch_size]
+            yield self.X[sel], self.y[sel]
+
+
+def breastmnist_splits():
+    """(train, val, test) of the committed BreastMNIST fixture through the data_loader mirror, flattened as
+    rbm_main.py:56-59 does it."""
+    from qbm_image_classification_amd import data_loader as dl
+
+    (trX, trY), (vaX, vaY), (teX, teY) = dl.get_medmnist(os.path.join(GOLDEN, "data_breastmnist.npz"))
+    tr, va, te = dl.preprocess_images(trX, vaX, teX)
+    return (tr, np.array(trY)), (va, np.array(vaY)), (te, np.array(teY))

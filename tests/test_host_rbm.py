@@ -85,3 +85,35 @@ def test_generative_and_hybrid_training_run_and_learn():
         assert False
     except NotImplementedError:
         pass
+
+
+def test_full_reference_run_reproduced_on_host_logic():
+    """The reference's real run configuration (rbm_main.py:32-33, :61-76: full BreastMNIST train split, H = 9, batch 7,
+    20 epochs, DataLoader(shuffle=True) after the same manual_seed) for the first seed, golden from the imported
+    reference (tools/make_golden_runs.py).  With the oracle standing in for the HIP ops: the torch DataLoader visits
+    the samples in the reference's order, test accuracy and AUC agree for EVERY epoch, parameters to 1e-5."""
+    from helpers import breastmnist_splits
+
+    g = golden("rbm_run_breast_h9.npz")
+    (tr, trY), _, (te, teY) = breastmnist_splits()
+    seed = int(g["seeds"][0])
+    np.random.seed(seed); torch.manual_seed(seed)
+    r = _rbm(784, int(g["H"]), 1, num_classes=2, learning_rate=float(g["lr"]), seed=seed)
+    assert np.array_equal(r.weights.numpy()[:4, :4], g[f"s{seed}_W0_corner"])
+    seen = []
+
+    class Logged(torch.utils.data.TensorDataset):
+        def __getitem__(self, i):
+            seen.append(int(i))
+            return super().__getitem__(i)
+
+    ds = Logged(torch.from_numpy(tr), torch.from_numpy(trY).long())
+    tl = torch.utils.data.DataLoader(ds, batch_size=int(g["batch"]), shuffle=True)          # rbm_main.py --host-loader
+    tel = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(torch.from_numpy(te), torch.from_numpy(teY).long()),
+                                      batch_size=len(ds), shuffle=False)
+    loss, _, nll = r.train_rbm(train_loader=tl, test_loader=tel, epochs=int(g["epochs"]), method="discriminative")
+    assert np.array_equal(np.array(seen).reshape(int(g["epochs"]), -1), g[f"s{seed}_order"])
+    assert np.array_equal(r.acc_per_epoch_list, g[f"s{seed}_acc"]) and np.array_equal(r.auc_per_epoch_list, g[f"s{seed}_auc"])
+    assert np.allclose(loss, g[f"s{seed}_loss"], rtol=0, atol=1e-6) and np.allclose(nll, g[f"s{seed}_nll"], rtol=0, atol=1e-6)
+    for k, a in (("W", r.weights), ("U", r.class_weights), ("d", r.hidden_bias), ("c", r.class_bias), ("b", r.visible_bias)):
+        assert np.max(np.abs(a.numpy() - g[f"s{seed}_{k}"])) <= 1e-5, k
