@@ -14,8 +14,8 @@ HBM before the timed region.  value = B * k * steps * N / time  (Gibbs samples/s
 full block-Gibbs sweep of one chain); visible-unit updates/s = 784 * value is printed alongside.
 
 The JSON line also carries `roofline` (dominant kernel, HIP-event timed inside this process) and
-`cpu_baseline` (the oracle -- a C/OpenMP restatement of the same algorithm -- on the host cores,
-rank 0, N = 1 only, bounded sample).
+`cpu_baseline` (a torch-CPU restatement of the same step in the reference's idiom on the host cores, with the
+bit-exact C/OpenMP oracle's timing as a secondary field; rank 0, N = 1 only, bounded sample).
 """
 from __future__ import annotations
 
@@ -199,13 +199,15 @@ def main():
         dom = max(timed, key=lambda k: timed[k] * kernels[k][2])   # most time per CD-1 step
         # HBM bytes per launch of that kernel from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate
         # rocprofv3 --pmc passes: tools/gpu_pmc_traffic.sh -> profiles/rNN_pmc_traffic.json); null if absent
-        traffic = None
+        traffic, traffic_source = None, None
         try:
             import glob
 
             newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]   # latest round's counters
             with open(newest) as f:
                 traffic = json.load(f)["kernels"][dom.split(" ")[0]]["hbm_bytes_per_launch"]
+            # NOT measured in this run: PMC counters need rocprofv3 around the process (tools/gpu_pmc_traffic.sh)
+            traffic_source = "imported from " + os.path.relpath(newest, ROOT) + " (rocprofv3 --pmc passes of this bench)"
         except (OSError, KeyError, ValueError, IndexError):
             pass
         fl = kernels[dom][1]
@@ -213,7 +215,7 @@ def main():
         alg_bytes = 4.0 * B * V + 8.0 * (V * H + V + H + NC * H + NC) + 4.0 * B    # SURVEY.md 8.D, per CD-1 step
         roofline = {
             "bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
             "avg_launch_us": round(timed[dom] * 1e6, 3),
             "all_kernels_us": {k: round(t * 1e6, 3) for k, t in timed.items()},
             "step_flops": (4 * K_CD + 6) * B * V * H + (4 * K_CD + 6) * B * NC * H,
@@ -257,13 +259,19 @@ def usable_cores() -> int:
 
 
 def cpu_baseline(budget_s: float):
-    """Same CD-1 step (same shapes, same Philox stream) on the oracle; `cores` = OpenMP threads used."""
+    """The same CD-1 step (same shapes, same synthetic inputs) on the host cores, bounded sample.
+    Primary: a torch-CPU restatement in the reference's idiom (oracle/rbm_torch_cpu.py: torch.matmul + elementwise ops,
+    torch.rand uniforms), torch.set_num_threads(usable cores) -- SURVEY.md 8.D / BASELINE.md section 3: "the repo's own
+    CPU trainer".  Secondary (`bit_exact_oracle`): the C/OpenMP oracle that the parity tests use; it pays for a fixed
+    summation order and a software Philox, so it is the slower of the two."""
     import numpy as np
+    import torch
 
     cores = usable_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)      # before libgomp starts: one thread per usable core
     os.environ.setdefault("OMP_WAIT_POLICY", "ACTIVE")
     from oracle import qbm_oracle as orc
+    from oracle.rbm_torch_cpu import TorchCpuRbm
 
     orc.build()
     rs = np.random.RandomState(42)
@@ -276,20 +284,34 @@ def cpu_baseline(budget_s: float):
     lab = np.minimum((orc.philox_uniform(4321, 0, 0, B, 1).reshape(-1) * NC).astype(np.int64), NC - 1)
     y0 = np.eye(NC, dtype=np.float32)[lab]
 
+    def timed(one, budget):
+        one(0)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget:
+            one(n + 1)
+            n += 1
+        return n, time.perf_counter() - t0
+
+    torch.manual_seed(0)
+    rbm = TorchCpuRbm(W, b, d, U, c, lr=0.05, threads=cores)
+    tv0, ty0 = torch.from_numpy(v0), torch.from_numpy(y0)
+    n_t, dt_t = timed(lambda i: rbm.cd1_step(tv0, ty0), 0.6 * budget_s)
+    assert torch.isfinite(rbm.W).all()
+
     def one(i):
         ph0, vk, yk, phk = orc.rbm_cd_chain(v0, y0, W, b, d, U, c, K_CD, 42, 4 * i, 0)
         g = orc.rbm_two_phase_grad(v0, y0, ph0, vk, yk, phk)
         orc.rbm_update(W, b, d, U, c, *g, 0.05, 1.0, float(B), 0.0)
 
-    one(0)
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
-        one(n + 1)
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": round(B * K_CD * n / dt, 1), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{n} CD-1 steps of the same 784x512, B=256 workload in {dt:.1f} s (oracle/qbm_oracle.c, OpenMP)",
-            "ms_per_step": round(dt / n * 1e3, 3)}
+    n_o, dt_o = timed(one, 0.4 * budget_s)
+    return {"value": round(B * K_CD * n_t / dt_t, 1), "unit": "samples/s", "cores": cores, "kind": "port",
+            "what": "torch-CPU restatement of the CD-1 step in the reference's idiom (oracle/rbm_torch_cpu.py), "
+                    f"torch.set_num_threads({cores})",
+            "sample": f"{n_t} CD-1 steps of the same 784x512, B=256, C=10 workload in {dt_t:.1f} s",
+            "ms_per_step": round(dt_t / n_t * 1e3, 3),
+            "bit_exact_oracle": {"value": round(B * K_CD * n_o / dt_o, 1), "unit": "samples/s", "cores": cores,
+                                 "sample": f"{n_o} CD-1 steps in {dt_o:.1f} s (oracle/qbm_oracle.c, OpenMP; the parity checker)",
+                                 "ms_per_step": round(dt_o / n_o * 1e3, 3)}}
 
 
 if __name__ == "__main__":

@@ -126,3 +126,26 @@ def test_discriminative_steps_match_reference(oracle, name):
     assert np.max(np.abs(d - g["d_after"])) <= 1e-5
     assert np.max(np.abs(U - g["U_after"])) <= 1e-5
     assert np.max(np.abs(c - g["c_after"])) <= 1e-5
+
+
+def test_torch_cpu_baseline_conditionals_match_reference_golden():
+    """bench.py's cpu_baseline leg (oracle/rbm_torch_cpu.py) computes the reference's conditionals: checked against the
+    imported reference's outputs (<= 1e-6), and one CD-1 step moves the parameters the right way."""
+    import torch
+
+    from oracle.rbm_torch_cpu import TorchCpuRbm
+
+    g = golden("rbm_prims_mid.npz")
+    V, H, C, B, seed = (int(g[k]) for k in ("V", "H", "C", "B", "seed"))
+    W, b, d, U, c = synth_params(V, H, C, seed)
+    v_bin, x_grey, h_bin, labels, y1h = synth_inputs(B, V, H, C, seed)
+    r = TorchCpuRbm(W, b, d, U, c, lr=0.05, threads=2)
+    t = torch.from_numpy
+    assert np.max(np.abs(r.p_hidden(t(v_bin), t(y1h)).numpy() - g["ph_bin"])) <= 1e-6
+    assert np.max(np.abs(r.p_visible(t(h_bin)).numpy() - g["pv"])) <= 1e-6
+    assert np.max(np.abs(r.p_class(t(h_bin)).numpy() - g["py"])) <= 1e-6
+    torch.manual_seed(0)
+    v1, y1, ph0, ph1 = r.cd1_step(t(v_bin), t(y1h))
+    assert set(np.unique(v1.numpy())) <= {0.0, 1.0} and (y1.sum(1) == 1).all()
+    want = W + 0.05 / B * (v_bin.T @ ph0.numpy() - v1.numpy().T @ ph1.numpy())
+    assert np.max(np.abs(r.W.numpy() - want)) <= 1e-5
