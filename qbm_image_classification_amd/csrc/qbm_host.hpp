@@ -9,6 +9,8 @@ namespace qbm {
 int fail(int code, const char* msg);             // records msg for qbm_last_error(), returns code
 int hip_fail(hipError_t e, const char* where);   // same, with hipGetErrorString; returns QBM_ERR_HIP
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
+inline bool aligned2(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 1u) == 0; }
 }  // namespace qbm
 
 #define QBM_CHECK_LAUNCH(where)                                      \

@@ -30,7 +30,11 @@ namespace {
 //   hidden  : [256 x 512], K = 784 -> 32 x 16 strips: 8 x 32 = 256 workgroups
 //   visible : [256 x 784], K = 512 -> 64 x 16 strips: 4 x 49 = 196 workgroups (+ 32 class workgroups)
 //   gradient: [784 x 512], K = 256 x 2 phases -> 64 x 32 strips: 13 x 16 = 208 workgroups (+ 30 for gU/gd/gb/gc)
-constexpr int H_MT = 2, H_NT = 1;
+#ifndef QBM_H_MT   // diagnostic variants (tools/stamp_kernels.py --variant) may override the hidden strip shape
+#define QBM_H_MT 2
+#define QBM_H_NT 1
+#endif
+constexpr int H_MT = QBM_H_MT, H_NT = QBM_H_NT;
 constexpr int V_MT = 4, V_NT = 1;
 constexpr int G_MT = 4, G_NT = 2;
 
@@ -82,99 +86,108 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
 {
     constexpr int MT = H_MT, NT = H_NT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    QBM_STAMP(10);
     const int nM = (a.B + 16 * MT - 1) / (16 * MT), nN = (a.H + 16 * NT - 1) / (16 * NT);
     int ms, ns;
     strip_coords(nM, nN, ms, ns);
     const int m0 = ms * 16 * MT, n0 = ns * 16 * NT;
     const typename KView<TA>::type A{reinterpret_cast<const TA*>(a.v), a.V, a.B};
     const ViewCContig Bv{a.W, a.H, a.H, a.V};
-    // Everything of the epilogue that does not depend on the contraction is done BEFORE it -- bias and class
-    // term loads (unconditional, indices clamped, so that they are all in flight together), the class chain
-    // (classes c >= C enter it as fmaf(0, u, cls), which is exact) and the Philox draw -- so that it overlaps
-    // the LDS-DMA of the operands instead of sitting in the tail of the kernel.
-    using SO = StripOut<MT, NT>;
-    float dv[SO::NP][4], cls[SO::NP][4];
-    f32x4 uu[SO::NP];
-#pragma unroll
-    for (int op = 0; op < SO::NP; ++op) {
-        const int i = min(m0 + SO::row(op), a.B - 1), j0 = n0 + 4 * SO::cg(op);
-        const bool vec = a.vecO && j0 + 3 < a.H;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) cls[op][e] = 0.f;
-        uu[op] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (vec) {
-            const float4 t = *reinterpret_cast<const float4*>(a.d + j0);
-            dv[op][0] = t.x; dv[op][1] = t.y; dv[op][2] = t.z; dv[op][3] = t.w;
+    // Epilogue map: the 32 x 16 strip has 512 outputs = 2 consecutive columns for each of the 256 threads.
+    using SO = StripOut<MT, NT, 2>;
+    static_assert(SO::NP == 1, "one output pair per thread");
+    const int row = m0 + SO::row(0), j0 = n0 + 2 * SO::cg(0);
+    const int i_c = min(row, a.B - 1);
+    const bool with_cls = MODE == 0 && a.y != nullptr;
+    const bool pair = a.vecO && j0 + 1 < a.H;     // 8-byte accesses
+    // Everything of the epilogue that does not depend on the contraction -- bias and class-term loads, the class chain
+    // (classes c >= C enter it as fmaf(0, u, cls), which is exact), the Philox draw -- is taken out of the tail of the
+    // kernel AND out of its head: the loads are issued in `pre0` (unconditional, indices clamped, untracked by the
+    // compiler: gload_*), i.e. behind the first operand transfers of the contraction, and consumed in `pre`, while those
+    // transfers are in flight.
+    uint32_t d_raw[2] = {0u, 0u}, y_raw[CM], u_raw[CM][2];
+    auto pre0 = [&]() {
+        if (pair) {
+            u32x2 t;
+            gload_b64(t, a.d + j0);
+            d_raw[0] = t[0]; d_raw[1] = t[1];
         } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) dv[op][e] = a.d[min(j0 + e, a.H - 1)];
+            gload_b32(d_raw[0], a.d + min(j0, a.H - 1));
+            gload_b32(d_raw[1], a.d + min(j0 + 1, a.H - 1));
         }
-        if (MODE == 0 && a.y) {
-            float yv[CM];
+        if (with_cls) {
 #pragma unroll
-            for (int c = 0; c < CM; ++c) {
-                const float t = a.y[(long)i * a.C + min(c, a.C - 1)];
-                yv[c] = (c < a.C) ? t : 0.f;
-            }
-            if (vec) {
-                float4 uv[CM];
-#pragma unroll
-                for (int c = 0; c < CM; ++c) uv[c] = *reinterpret_cast<const float4*>(a.U + (long)min(c, a.C - 1) * a.H + j0);
+            for (int c = 0; c < CM; ++c) gload_b32(y_raw[c], a.y + (long)i_c * a.C + min(c, a.C - 1));
+            if (pair) {
 #pragma unroll
                 for (int c = 0; c < CM; ++c) {
-                    cls[op][0] = __builtin_fmaf(yv[c], uv[c].x, cls[op][0]);
-                    cls[op][1] = __builtin_fmaf(yv[c], uv[c].y, cls[op][1]);
-                    cls[op][2] = __builtin_fmaf(yv[c], uv[c].z, cls[op][2]);
-                    cls[op][3] = __builtin_fmaf(yv[c], uv[c].w, cls[op][3]);
+                    u32x2 t;
+                    gload_b64(t, a.U + (long)min(c, a.C - 1) * a.H + j0);
+                    u_raw[c][0] = t[0]; u_raw[c][1] = t[1];
                 }
             } else {
 #pragma unroll
-                for (int c = 0; c < CM; ++c)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        cls[op][e] = __builtin_fmaf(yv[c], a.U[(long)min(c, a.C - 1) * a.H + min(j0 + e, a.H - 1)], cls[op][e]);
+                for (int c = 0; c < CM; ++c) {
+                    gload_b32(u_raw[c][0], a.U + (long)min(c, a.C - 1) * a.H + min(j0, a.H - 1));
+                    gload_b32(u_raw[c][1], a.U + (long)min(c, a.C - 1) * a.H + min(j0 + 1, a.H - 1));
+                }
             }
         }
-        if (MODE == 0 && (a.s || a.s8))
-            uu[op] = uniform4(a.seed, a.offset, a.row0 + (uint32_t)(m0 + SO::row(op)), (uint32_t)(j0 >> 2));
-        // keep the draw here (the compiler would sink ~100 VALU instructions into the epilogue, behind the contraction):
-        // this way it runs while the loads above and the first LDS-DMA transfers are in flight
-        asm volatile("" : "+v"(uu[op]));
-    }
-    const auto o = strip_mma<MT, NT, FAST, FAST>(A, Bv, m0, n0, a.V, lds, a.KP);
+    };
+    float dv[2], cls[2] = {0.f, 0.f}, uu[2] = {0.f, 0.f};
+    auto pre = [&](int n_younger) {
+        if (MODE == 0 && (a.s || a.s8)) {
+            // one Philox block serves columns 4*(j0>>2) .. +3; this thread's pair is its lower or upper half
+            uint32_t prow = a.row0 + (uint32_t)row;
+            asm volatile("" : "+v"(prow));   // the draw depends on this statement's position: it cannot be hoisted above the transfers
+            const f32x4 u4 = uniform4(a.seed, a.offset, prow, (uint32_t)(j0 >> 2));
+            uu[0] = (j0 & 2) ? u4[2] : u4[0];
+            uu[1] = (j0 & 2) ? u4[3] : u4[1];
+            asm volatile("" : "+v"(uu[0]), "+v"(uu[1]));   // ... nor sunk behind the wait below
+        }
+        vm_wait(n_younger);   // the loads of pre0 (and everything older) have landed; n_younger transfers stay in flight
+        asm volatile("" : "+v"(d_raw[0]), "+v"(d_raw[1]));
+        dv[0] = __uint_as_float(d_raw[0]); dv[1] = __uint_as_float(d_raw[1]);
+        if (with_cls) {
 #pragma unroll
-    for (int op = 0; op < o.NP; ++op) {
-        if (!o.valid(op)) continue;
-        const int i = m0 + o.row(op), j0 = n0 + 4 * o.cg(op);
-        if (i >= a.B || j0 >= a.H) continue;
-        const bool vec = a.vecO && j0 + 3 < a.H;
-        const float sv[4] = {o.sum[op].x, o.sum[op].y, o.sum[op].z, o.sum[op].w};
-        float pv[4], hv[4];
+            for (int c = 0; c < CM; ++c) {
+                asm volatile("" : "+v"(y_raw[c]), "+v"(u_raw[c][0]), "+v"(u_raw[c][1]));
+                const float yv = (c < a.C) ? __uint_as_float(y_raw[c]) : 0.f;
+                cls[0] = __builtin_fmaf(yv, __uint_as_float(u_raw[c][0]), cls[0]);
+                cls[1] = __builtin_fmaf(yv, __uint_as_float(u_raw[c][1]), cls[1]);
+            }
+        }
+    };
+    QBM_STAMP(11);
+    const auto o = strip_mma<MT, NT, FAST, FAST, 2>(A, Bv, m0, n0, a.V, lds, a.KP, pre0, pre);
+    if (o.valid(0) && row < a.B && j0 < a.H) {
+        const float sv[2] = {o.sum[0].x, o.sum[0].y};
+        float pv[2], hv[2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float x = sv[e] + dv[op][e];
+        for (int e = 0; e < 2; ++e) {
+            float x = sv[e] + dv[e];
             if (MODE == 0) {
-                if (a.y) x = x + cls[op][e];
+                if (a.y) x = x + cls[e];
                 pv[e] = det_sigmoid(x);
-                hv[e] = (pv[e] > uu[op][e]) ? 1.f : 0.f;
+                hv[e] = (pv[e] > uu[e]) ? 1.f : 0.f;
             } else {
                 pv[e] = x; hv[e] = 0.f;
             }
         }
-        const long off = (long)i * a.H + j0;
-        if (vec) {
-            if (a.p) *reinterpret_cast<float4*>(a.p + off) = make_float4(pv[0], pv[1], pv[2], pv[3]);
-            if (MODE == 0 && a.s) *reinterpret_cast<float4*>(a.s + off) = make_float4(hv[0], hv[1], hv[2], hv[3]);
-            if (MODE == 0 && a.s8)
-                *reinterpret_cast<uint32_t*>(a.s8 + off) = (uint32_t)hv[0] | ((uint32_t)hv[1] << 8) | ((uint32_t)hv[2] << 16) | ((uint32_t)hv[3] << 24);
+        const long off = (long)row * a.H + j0;
+        if (pair) {
+            if (a.p) *reinterpret_cast<float2*>(a.p + off) = make_float2(pv[0], pv[1]);
+            if (MODE == 0 && a.s) *reinterpret_cast<float2*>(a.s + off) = make_float2(hv[0], hv[1]);
+            if (MODE == 0 && a.s8) *reinterpret_cast<uint16_t*>(a.s8 + off) = (uint16_t)((uint32_t)hv[0] | ((uint32_t)hv[1] << 8));
         } else {
-            for (int e = 0; e < 4 && j0 + e < a.H; ++e) {
+            for (int e = 0; e < 2 && j0 + e < a.H; ++e) {
                 if (a.p) a.p[off + e] = pv[e];
                 if (MODE == 0 && a.s) a.s[off + e] = hv[e];
                 if (MODE == 0 && a.s8) a.s8[off + e] = (uint8_t)hv[e];
             }
         }
     }
+    QBM_STAMP(12);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -291,31 +304,44 @@ __global__ __launch_bounds__(256) void k_visible(VisibleArgs a)
         return;
     }
     constexpr int MT = V_MT, NT = V_NT;
+    QBM_STAMP(10);
     const int nM = (a.B + 16 * MT - 1) / (16 * MT), nN = (a.V + 16 * NT - 1) / (16 * NT);
     int ms, ns;
     strip_coords(nM, nN, ms, ns, a.n_aux);
     const int m0 = ms * 16 * MT, n0 = ns * 16 * NT;
     const typename KView<TA>::type A{reinterpret_cast<const TA*>(a.h), a.H, a.B};
     const ViewKContig Bv{a.W, a.H, a.V};
-    // bias loads and the Philox draw do not depend on the contraction: issue them before it
+    // The bias loads are issued behind the first operand transfers (`pre0`) and consumed in the epilogue; the Philox draw
+    // runs in `pre`, while the transfers are in flight.
     using SO = StripOut<MT, NT>;
     float bv[SO::NP][4];
     f32x4 uu[SO::NP];
+    auto pre0 = [&]() {
 #pragma unroll
-    for (int op = 0; op < SO::NP; ++op) {
-        const int k0 = n0 + 4 * SO::cg(op);
-        if (a.vecO && k0 + 3 < a.V) {
-            const float4 t = *reinterpret_cast<const float4*>(a.b + k0);
-            bv[op][0] = t.x; bv[op][1] = t.y; bv[op][2] = t.z; bv[op][3] = t.w;
-        } else {
+        for (int op = 0; op < SO::NP; ++op) {
+            const int k0 = n0 + 4 * SO::cg(op);
+            if (a.vecO && k0 + 3 < a.V) {
+                const float4 t = *reinterpret_cast<const float4*>(a.b + k0);
+                bv[op][0] = t.x; bv[op][1] = t.y; bv[op][2] = t.z; bv[op][3] = t.w;
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bv[op][e] = a.b[min(k0 + e, a.V - 1)];
+                for (int e = 0; e < 4; ++e) bv[op][e] = a.b[min(k0 + e, a.V - 1)];
+            }
         }
-        uu[op] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (a.s || a.s8) uu[op] = uniform4(a.seed, a.offset, a.row0 + (uint32_t)(m0 + SO::row(op)), (uint32_t)(k0 >> 2));
-        asm volatile("" : "+v"(uu[op]));   // pinned in front of the contraction (see k_hidden)
-    }
-    const auto o = strip_mma<MT, NT, FAST, FAST>(A, Bv, m0, n0, a.H, lds, a.KP);
+    };
+    auto pre = [&](int) {
+#pragma unroll
+        for (int op = 0; op < SO::NP; ++op) {
+            const int k0 = n0 + 4 * SO::cg(op);
+            uu[op] = f32x4{0.f, 0.f, 0.f, 0.f};
+            uint32_t prow = a.row0 + (uint32_t)(m0 + SO::row(op));
+            asm volatile("" : "+v"(prow));     // the draw depends on this statement's position: not hoisted above the transfers,
+            if (a.s || a.s8) uu[op] = uniform4(a.seed, a.offset, prow, (uint32_t)(k0 >> 2));
+            asm volatile("" : "+v"(uu[op]));   // not sunk into the epilogue
+        }
+    };
+    QBM_STAMP(11);
+    const auto o = strip_mma<MT, NT, FAST, FAST>(A, Bv, m0, n0, a.H, lds, a.KP, pre0, pre);
 #pragma unroll
     for (int op = 0; op < o.NP; ++op) {
         if (!o.valid(op)) continue;
@@ -343,6 +369,7 @@ __global__ __launch_bounds__(256) void k_visible(VisibleArgs a)
             }
         }
     }
+    QBM_STAMP(12);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -546,6 +573,7 @@ __global__ __launch_bounds__(256) void k_grad(GradArgs a)
 {
     constexpr int MT = G_MT, NT = G_NT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    QBM_STAMP(10);
     int blk = blockIdx.x;
     const ViewCContig P0{a.P0, a.H, a.H, a.B}, P1{a.P1, a.H, a.H, a.B};
     const typename CView<T0>::type D0{reinterpret_cast<const T0*>(a.A0), a.V, a.V, a.B};
@@ -619,8 +647,20 @@ __global__ __launch_bounds__(256) void k_grad(GradArgs a)
     int ms, ns;
     strip_coords(nM, nN, ms, ns, a.nU + a.nB + a.nC);
     const int m0 = ms * 16 * MT, n0 = ns * 16 * NT;
-    const auto o0 = strip_mma<MT, NT, FAST, FAST>(D0, P0, m0, n0, a.B, lds, a.KP);
-    const auto o1 = strip_mma<MT, NT, FAST, FAST>(D1, P1, m0, n0, a.B, lds, a.KP);
+    // fused update: the W tile is requested behind the first operand transfers and consumed in the epilogue
+    using SO = StripOut<MT, NT>;
+    float4 w_old[SO::NP];
+    auto pre0 = [&]() {
+#pragma unroll
+        for (int op = 0; op < SO::NP; ++op) {
+            const int m = min(m0 + SO::row(op), a.V - 1), nb = n0 + 4 * SO::cg(op);
+            w_old[op] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.W && a.vecO && nb + 3 < a.H) w_old[op] = *reinterpret_cast<const float4*>(a.W + (long)m * a.H + nb);
+        }
+    };
+    QBM_STAMP(11);
+    const auto o0 = strip_mma<MT, NT, FAST, FAST>(D0, P0, m0, n0, a.B, lds, a.KP, pre0);
+    const auto o1 = strip_mma<MT, NT, FAST, FAST>(D1, P1, m0, n0, a.B, lds, a.KP, NoPre{}, NoPre{}, 5);
 #pragma unroll
     for (int op = 0; op < o0.NP; ++op) {
         if (!o0.valid(op)) continue;
@@ -632,7 +672,7 @@ __global__ __launch_bounds__(256) void k_grad(GradArgs a)
         if (nb + 3 < a.H && a.vecO) {
             if (a.gW) *reinterpret_cast<float4*>(a.gW + off) = make_float4(g[0], g[1], g[2], g[3]);
             if (a.W) {
-                float4 w = *reinterpret_cast<const float4*>(a.W + off);
+                float4 w = w_old[op];
                 w.x = upd(w.x, g[0], a, false); w.y = upd(w.y, g[1], a, false);
                 w.z = upd(w.z, g[2], a, false); w.w = upd(w.w, g[3], a, false);
                 *reinterpret_cast<float4*>(a.W + off) = w;
@@ -644,6 +684,7 @@ __global__ __launch_bounds__(256) void k_grad(GradArgs a)
             if (a.W) a.W[off + e] = upd(a.W[off + e], g[e], a, false);
         }
     }
+    QBM_STAMP(12);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -760,8 +801,9 @@ int launch_hidden_t(const qbm_rbm_params* P, const void* v, const float* y, int 
 {
     constexpr int ASZ = (int)sizeof(TA), MT = H_MT, NT = H_NT;
     HiddenArgs a{v, y, P->W, P->d, P->U, p, s, s8, B, P->V, P->H, P->C, panel_for<MT, NT, ASZ>(P->V), seed, offset, row0,
-                 (P->H % 4 == 0) && (!p || aligned16(p)) && (!s || aligned16(s)) && (!s8 || aligned16(s8)) &&
-                     aligned16(P->d) && aligned16(P->U)};
+                 // column pairs: 8-byte accesses to p / h_f32 / d / U, 2-byte accesses to h_u8
+                 (P->H % 2 == 0) && (!p || aligned8(p)) && (!s || aligned8(s)) && (!s8 || aligned2(s8)) &&
+                     aligned8(P->d) && aligned8(P->U)};
     // LDS-DMA path: whole 16-k pieces, 16-byte aligned units, descriptors below 2 GiB
     const bool fast = (P->V % 16 == 0) && aligned16(v) && (P->H % 4 == 0) && aligned16(P->W) &&
                       small2g((long)B * P->V, ASZ) && small2g((long)P->V * P->H, 4);
@@ -1104,6 +1146,22 @@ int qbm_rbm_disc_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const flo
     }
     return QBM_OK;
 }
+
+#ifdef QBM_DIAG_STAMPS
+// diagnostic library only (tools/stamp_kernels.py): the s_memtime stamps of the last launches, 16 slots per wave
+QBM_API int qbm_diag_read_stamps(unsigned long long* host_out, int n_waves)
+{
+    if (n_waves > kStampWaves) n_waves = kStampWaves;
+    hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16 * (size_t)n_waves);
+    return e == hipSuccess ? QBM_OK : hip_fail(e, "hipMemcpyFromSymbol(g_stamps)");
+}
+QBM_API int qbm_diag_clear_stamps(void)
+{
+    static unsigned long long zeros[kStampWaves * 16];
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zeros, sizeof(zeros));
+    return e == hipSuccess ? QBM_OK : hip_fail(e, "hipMemcpyToSymbol(g_stamps)");
+}
+#endif
 
 int qbm_test_math(int which, const float* x, float* y, int n, void* stream)
 {

@@ -30,8 +30,20 @@
 #include "qbm_device.hip.h"
 #include <type_traits>
 
-// diagnostic builds (tools/microbench) define QBM_STAMP(i) to record s_memtime at phase boundaries;
-// in the product it expands to nothing
+// Diagnostic builds record s_memtime at phase boundaries: tools/microbench defines its own QBM_STAMP(i), and
+// -DQBM_DIAG_STAMPS (tools/stamp_kernels.py builds the real kernels that way into a library of its own, never into
+// libqbm_hip.so) stamps slot i of 16 per wave.  In the product QBM_STAMP expands to nothing.
+#ifdef QBM_DIAG_STAMPS
+#include <hip/hip_runtime.h>
+namespace qbm { constexpr int kStampWaves = 8192; static __device__ unsigned long long g_stamps[kStampWaves * 16]; }
+#define QBM_STAMP(i)                                                                                          \
+    do {                                                                                                      \
+        unsigned long long t__;                                                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                          \
+        const unsigned w__ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                             \
+        if ((threadIdx.x & 63) == 0 && w__ < (unsigned)qbm::kStampWaves) qbm::g_stamps[w__ * 16 + (i)] = t__; \
+    } while (0)
+#endif
 #ifndef QBM_STAMP
 #define QBM_STAMP(i)
 #endif
@@ -40,6 +52,10 @@
 // whatever the LDS holds).  0 in the product (the branches fold away).
 #ifndef QBM_DIAG_MODE
 #define QBM_DIAG_MODE 0
+#endif
+// 1: request every LDS-DMA transfer of a panel before its first MFMA; 0: two quads ahead of the MFMAs
+#ifndef QBM_DMA_ALL_UPFRONT
+#define QBM_DMA_ALL_UPFRONT 0
 #endif
 
 namespace qbm {
@@ -272,16 +288,41 @@ __host__ __device__ constexpr int strip_max_panel()
     return kp;
 }
 
-// What one thread holds after the four partial strips are combined: NP = ceil(MT*NT/4) outputs; output p of
-// thread t is row (t + 256p) / (4*NT), column group (t + 256p) % (4*NT) of the strip (4 consecutive columns),
-// sum[p] = ((q0+q1)+q2)+q3.
-template <int MT, int NT>
+// What one thread holds after the four partial strips are combined.  CPT = consecutive columns per output (4, or 2
+// for strips so small that 4 columns per thread would leave half of the workgroup without an epilogue):
+// NP = ceil(MT*NT*64 / (64*CPT)) outputs; output p of thread t is row (t + 256p) / (16*NT/CPT), column group
+// (t + 256p) % (16*NT/CPT) of the strip (columns CPT*cg .. CPT*cg + CPT - 1), sum[p] = ((q0+q1)+q2)+q3
+// (CPT == 2: in .x, .y).
+template <int MT, int NT, int CPT = 4>
 struct StripOut {
-    static constexpr int NP = (MT * NT + 3) / 4;
+    static_assert(CPT == 4 || CPT == 2, "4 or 2 columns per thread");
+    static constexpr int kCG = 16 * NT / CPT;                       // column groups per strip row
+    static constexpr int NP = (16 * MT * kCG + 255) / 256;
     float4 sum[NP];
-    __device__ __forceinline__ static bool valid(int p) { return (int)threadIdx.x + 256 * p < 64 * MT * NT; }
-    __device__ __forceinline__ static int row(int p) { return ((int)threadIdx.x + 256 * p) / (4 * NT); }
-    __device__ __forceinline__ static int cg(int p) { return ((int)threadIdx.x + 256 * p) % (4 * NT); }
+    __device__ __forceinline__ static bool valid(int p) { return (int)threadIdx.x + 256 * p < 16 * MT * kCG; }
+    __device__ __forceinline__ static int row(int p) { return ((int)threadIdx.x + 256 * p) / kCG; }
+    __device__ __forceinline__ static int cg(int p) { return ((int)threadIdx.x + 256 * p) % kCG; }
+};
+
+// Loads whose consumer sits behind an explicit vm_wait(): the compiler's wait-count pass does not see them, so it
+// does not park the wave on them where they are issued.  The destination registers must not be touched before
+// that wait (tie them with `asm volatile("" : "+v"(x))` right behind it).
+__device__ __forceinline__ void gload_b32(uint32_t& dst, const void* p)
+{
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void gload_b64(u32x2& dst, const void* p)
+{
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void gload_b128(u32x4& dst, const void* p)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+
+// `pre` hook of strip_mma that does nothing
+struct NoPre {
+    __device__ __forceinline__ void operator()(int) const {}
 };
 
 // wait until at most n of this wave's vector-memory operations (LDS-DMA pieces included) are outstanding.
@@ -306,10 +347,17 @@ __device__ __forceinline__ void vm_wait(int n)
 // KP: panel length, multiple of 64.  lds: the workgroup's dynamic LDS (strip_lds_bytes<MT,NT,sizeof(elem)>(KP)).
 // FAST_A / FAST_B: the operand is staged by LDS-DMA (the host guarantees alignment and whole 16-byte units);
 // otherwise its values go through registers (any shape, any alignment, synthesised operands).
-template <int MT, int NT, bool FAST_A, bool FAST_B, class AView, class BView>
-__device__ __forceinline__ StripOut<MT, NT> strip_mma(const AView& A, const BView& Bv, int m0, int n0, int K,
-                                              char* __restrict__ lds, int KP)
+// pre(n): called ONCE by every wave, right after its first LDS-DMA transfers have been issued (n = how many vector-memory
+// instructions this wave has issued inside strip_mma until then; 0 on the register-staged path, where the hook runs
+// first).  It is the place for the caller's contraction-independent work (bias / class-term loads issued before the call
+// and consumed here behind vm_wait(n), the Philox draw): that work then runs while the first operand tiles are in flight
+// instead of in front of them.
+template <int MT, int NT, bool FAST_A, bool FAST_B, int CPT = 4, class AView, class BView, class Pre = NoPre>
+__device__ __forceinline__ StripOut<MT, NT, CPT> strip_mma(const AView& A, const BView& Bv, int m0, int n0, int K,
+                                                           char* __restrict__ lds, int KP, Pre&& pre = NoPre{},
+                                                           int stamp0 = 0)
 {
+    (void)stamp0;   // first stamp slot of this call (diagnostic builds only)
     using TA = typename AView::elem;
     const int qbm_diag = QBM_DIAG_MODE;   // 0 in the product: the diagnostic branches fold away
     constexpr bool A8 = sizeof(TA) == 1;
@@ -333,7 +381,7 @@ __device__ __forceinline__ StripOut<MT, NT> strip_mma(const AView& A, const BVie
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    QBM_STAMP(0);
+    QBM_STAMP(stamp0 + 0);
 
     const int fragB = (B_K4 ? ((lane & 15) * 4 + (lane >> 4)) : lane) * 4;                  // byte offset in a piece
     const int fragA = A8 ? (A_K4 ? (lane & 15) * 16 + (lane >> 4) : (lane >> 4) * 16 + (lane & 15))  // u8: see header
@@ -499,6 +547,35 @@ __device__ __forceinline__ StripOut<MT, NT> strip_mma(const AView& A, const BVie
             const int quads = (pieces + 3) >> 2;
             auto quad_pieces = [&](int qd) { return min(4, pieces - 4 * qd); };
             auto quad_dmas = [&](int qd) { return qd < quads ? (A8 ? MT : MT * quad_pieces(qd)) + NT * quad_pieces(qd) : 0; };
+#ifdef QBM_HACK_FULL_LINES
+            // TIMING-ONLY experiment (wrong results): K-contiguous operands requested as 8 rows x 128 B per instruction
+            // instead of 16 rows x 64 B -- the same bytes, half the cache-line requests
+            auto issue_quad = [&](int qd) {
+                const int np = quad_pieces(qd);
+                if constexpr (A8 && A_K4) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        const unsigned v = (unsigned)((m0 + 16 * i + (lane & 7) + 8 * (qd & 1)) * (int)A.ld + kb + 128 * (qd >> 1) + 16 * (lane >> 3));
+                        blds16(ra, v, imgA + i * a_tile + qd * 1024);
+                    }
+                }
+                for (int pc = 4 * qd; pc < 4 * qd + np; ++pc) {
+                    if constexpr (B_K4) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const unsigned v = (unsigned)(((n0 + 16 * t + (lane & 7) + 8 * (pc & 1)) * (int)Bv.ld + kb + 32 * (pc >> 1) + 4 * (lane >> 3)) * 4);
+                            blds16(rb, v, imgB + t * b_tile + pc * 1024);
+                        }
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            blds16(rb, lb[t].voff, imgB + t * b_tile + pc * 1024);
+                            lb[t].voff += lb[t].step;
+                        }
+                    }
+                }
+            };
+#else
             auto issue_quad = [&](int qd) {
                 const int np = quad_pieces(qd);
                 if constexpr (A8) {
@@ -525,11 +602,29 @@ __device__ __forceinline__ StripOut<MT, NT> strip_mma(const AView& A, const BVie
                     }
                 }
             };
+#endif
+#if QBM_DMA_ALL_UPFRONT
+            // every transfer of the panel is requested before the first MFMA (the panel's LDS image holds all of it, and
+            // strip_max_panel keeps the request count inside the vmcnt range): no LDS-DMA issue -- which blocks the wave while
+            // the memory pipeline is full -- sits between the MFMAs; the wait before quad qd leaves the later quads in flight
+            int pend = 0;
+            for (int j = 0; j < quads; ++j) { issue_quad(j); pend += quad_dmas(j); }
+            QBM_STAMP(stamp0 + 1);
+            if (kb == kq0) pre(pend);
+            for (int qd = 0; qd < quads; ++qd) {
+                pend -= quad_dmas(qd);
+                vm_wait(pend);
+                if (qd == 0) QBM_STAMP(stamp0 + 2);
+                if (quad_pieces(qd) == 4) run_quad_n(std::integral_constant<int, 4>{}, qd);
+                else run_quad(qd, quad_pieces(qd));
+            }
+#else
             if (qbm_diag != 4) {
                 if (quads > 0) issue_quad(0);
                 if (quads > 1) issue_quad(1);
             }
-            QBM_STAMP(1);
+            QBM_STAMP(stamp0 + 1);
+            if (kb == kq0) pre(quad_dmas(0) + quad_dmas(1));
             // Full quads run in one loop body (one code path: the accumulators stay in place); the wait before quad qd
             // leaves the transfers of quads qd+1, qd+2 in flight, counted with constants (a full quad is kFull DMA
             // instructions; the tail quad is counted as none, which only waits a little longer than necessary).
@@ -545,16 +640,18 @@ __device__ __forceinline__ StripOut<MT, NT> strip_mma(const AView& A, const BVie
                     else if (qd + 1 < full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kFull) : "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
-                if (qd == 0) QBM_STAMP(2);
+                if (qd == 0) QBM_STAMP(stamp0 + 2);
                 if (qbm_diag != 3) run_quad_n(std::integral_constant<int, 4>{}, qd);
             }
             if (qd < quads) {   // tail quad: 1..3 pieces, nothing is in flight behind it
                 if (qbm_diag != 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (qd == 0) QBM_STAMP(2);
+                if (qd == 0) QBM_STAMP(stamp0 + 2);
                 if (qbm_diag != 3) run_quad(qd, pieces - 4 * qd);
             }
+#endif
         } else {
             // ---- at least one operand goes through registers (unaligned / ragged / synthesised)
+            if (kb == kq0) pre(0);
             const int quads = (pieces + 3) >> 2;
             if constexpr (FAST_A) {
                 const rsrc_t ra = A.rsrc();
@@ -594,12 +691,12 @@ __device__ __forceinline__ StripOut<MT, NT> strip_mma(const AView& A, const BVie
                     for (int t = 0; t < NT; ++t)
                         reinterpret_cast<float4*>(imgB + t * b_tile)[pc * 64 + lane] = Bv.get(n0 + 16 * t, kb, kend, pc * 64 + lane);
             }
-            QBM_STAMP(1);
+            QBM_STAMP(stamp0 + 1);
             if constexpr (FAST_A || FAST_B) vm_wait(0);
-            QBM_STAMP(2);
+            QBM_STAMP(stamp0 + 2);
             run(0, pieces);
         }
-        QBM_STAMP(3);
+        QBM_STAMP(stamp0 + 3);
     }
 
     // partial strips -> LDS (each wave reuses the head of its own staging region), row-major
@@ -614,23 +711,32 @@ __device__ __forceinline__ StripOut<MT, NT> strip_mma(const AView& A, const BVie
             for (int r = 0; r < 4; ++r) red[(16 * i + (lane >> 4) * 4 + r) * RS + 16 * t + (lane & 15)] = acc[i][t][r];
     __syncthreads();
 
-    StripOut<MT, NT> o;
+    StripOut<MT, NT, CPT> o;
 #pragma unroll
-    for (int p = 0; p < StripOut<MT, NT>::NP; ++p) {
+    for (int p = 0; p < StripOut<MT, NT, CPT>::NP; ++p) {
         o.sum[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (o.valid(p)) {
-            const char* base = lds + (size_t)(o.row(p) * RS + 4 * o.cg(p)) * 4;
-            const float4 p0 = *reinterpret_cast<const float4*>(base);
-            const float4 p1 = *reinterpret_cast<const float4*>(base + wave_bytes);
-            const float4 p2 = *reinterpret_cast<const float4*>(base + 2 * (size_t)wave_bytes);
-            const float4 p3 = *reinterpret_cast<const float4*>(base + 3 * (size_t)wave_bytes);
-            o.sum[p].x = ((p0.x + p1.x) + p2.x) + p3.x;
-            o.sum[p].y = ((p0.y + p1.y) + p2.y) + p3.y;
-            o.sum[p].z = ((p0.z + p1.z) + p2.z) + p3.z;
-            o.sum[p].w = ((p0.w + p1.w) + p2.w) + p3.w;
+            const char* base = lds + (size_t)(o.row(p) * RS + CPT * o.cg(p)) * 4;
+            if constexpr (CPT == 4) {
+                const float4 p0 = *reinterpret_cast<const float4*>(base);
+                const float4 p1 = *reinterpret_cast<const float4*>(base + wave_bytes);
+                const float4 p2 = *reinterpret_cast<const float4*>(base + 2 * (size_t)wave_bytes);
+                const float4 p3 = *reinterpret_cast<const float4*>(base + 3 * (size_t)wave_bytes);
+                o.sum[p].x = ((p0.x + p1.x) + p2.x) + p3.x;
+                o.sum[p].y = ((p0.y + p1.y) + p2.y) + p3.y;
+                o.sum[p].z = ((p0.z + p1.z) + p2.z) + p3.z;
+                o.sum[p].w = ((p0.w + p1.w) + p2.w) + p3.w;
+            } else {
+                const float2 p0 = *reinterpret_cast<const float2*>(base);
+                const float2 p1 = *reinterpret_cast<const float2*>(base + wave_bytes);
+                const float2 p2 = *reinterpret_cast<const float2*>(base + 2 * (size_t)wave_bytes);
+                const float2 p3 = *reinterpret_cast<const float2*>(base + 3 * (size_t)wave_bytes);
+                o.sum[p].x = ((p0.x + p1.x) + p2.x) + p3.x;
+                o.sum[p].y = ((p0.y + p1.y) + p2.y) + p3.y;
+            }
         }
     }
-    QBM_STAMP(4);
+    QBM_STAMP(stamp0 + 4);
     __syncthreads();  // the partials are consumed: the caller may run another contraction on this LDS
     return o;
 }

@@ -1,0 +1,120 @@
+#!/usr/bin/env python
+"""tools/stamp_kernels.py -- where the cycles of the REAL strip kernels go (diagnostic; GPU box).
+
+Builds csrc/rbm_kernels.hip with -DQBM_DIAG_STAMPS into tools/microbench/bin/libqbm_stamp.so (never into the product
+library), launches k_hidden / k_visible / k_grad at the benchmark shape (784 x 512, B = 256, C = 10, uint8 states)
+and prints, per kernel, the median / p10 / p90 over waves of the s_memtime differences between the stamp slots:
+
+  10 kernel entry   11 before the contraction (prologue done)   0 strip_mma entry   1 first LDS-DMA issued
+  2 first quad landed   3 MFMA loop done   4 partial strips combined   12 kernel exit
+  (k_grad: the second contraction uses slots 5..9)
+
+    python tools/stamp_kernels.py [--build-only]
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CSRC = os.path.join(ROOT, "qbm_image_classification_amd", "csrc")
+SO = os.path.join(ROOT, "tools", "microbench", "bin", "libqbm_stamp.so")
+
+
+def build(extra=(), so=None):
+    from qbm_image_classification_amd.build import FLAGS
+
+    so = so or SO
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + FLAGS + ["-DQBM_DIAG_STAMPS", *extra, os.path.join(CSRC, "rbm_kernels.hip"), "-o", so]
+    subprocess.check_call(cmd)
+    return so
+
+
+def main():
+    global SO
+    variant = [a for a in sys.argv[1:] if a.startswith("--variant=")]
+    if variant:      # --variant=name:-DFLAG=1,-DOTHER=2  -> a stamped library of its own
+        name, _, flags = variant[0][len("--variant="):].partition(":")
+        SO = SO.replace(".so", f"_{name}.so")
+        if not os.path.exists(SO) or "--build-only" in sys.argv:
+            build([f for f in flags.split(",") if f], SO)
+    elif not os.path.exists(SO) or "--build-only" in sys.argv:
+        build()
+    if "--build-only" in sys.argv:
+        return
+    import numpy as np
+    import torch
+
+    from qbm_image_classification_amd import _lib
+
+    lib = C.CDLL(SO)
+    for name, argtypes in _lib.SIGNATURES.items():
+        if name.startswith("qbm_rbm_"):       # this library holds the rbm_kernels.hip translation unit only
+            getattr(lib, name).argtypes = argtypes
+    lib.qbm_diag_read_stamps.argtypes = [C.c_void_p, C.c_int]
+    V, H, NC, B = 784, 512, 10, 256
+    dev = torch.device("cuda:0")
+    torch.manual_seed(42)
+    t = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    wld = int(os.environ.get("QBM_HACK_WLD", H))      # timing-only experiment: padded row pitch of W
+    W = (torch.randn(V, wld) * 0.1).to(dev)
+    b, d, U, c = torch.full((V,), 0.5, device=dev), torch.zeros(H, device=dev), torch.zeros(NC, H, device=dev), torch.zeros(NC, device=dev)
+    P = _lib.RbmParams(*(C.c_void_p(x.data_ptr()) for x in (W, b, d, U, c)), V, H, NC)
+    v0 = (torch.rand(B, V, device=dev) < 0.5).to(torch.uint8)
+    y0 = torch.nn.functional.one_hot(torch.randint(0, NC, (B,), device=dev), NC).float()
+    ph0, phk, h, vk, yk = t(B, H), t(B, H), torch.empty(B, H, dtype=torch.uint8, device=dev), torch.empty(B, V, dtype=torch.uint8, device=dev), t(B, NC)
+    gW, gb, gd, gU, gc = t(V, H), t(V), t(H), t(NC, H), t(NC)
+    G = _lib.RbmGrads(None, *(C.c_void_p(x.data_ptr()) for x in (gb, gd, gU, gc)))
+    Wsc = W.clone()
+    p = lambda x: C.c_void_p(x.data_ptr())
+    kernels = {
+        "k_hidden": (lambda: lib.qbm_rbm_sample_hidden_ex(C.byref(P), p(v0), 1, p(y0), B, p(ph0), None, p(h), 42, 0, 0, None), 256 * 4),
+        "k_visible": (lambda: lib.qbm_rbm_sample_visible_class_ex(C.byref(P), p(h), 1, B, None, None, p(vk), None, p(yk), 42, 1, 2, 0, None), (196 + 256) * 4),
+        "k_grad": (lambda: lib.qbm_rbm_two_phase_grad(V, H, NC, B, p(v0), 1, p(y0), p(ph0), p(vk), 1, p(yk), p(phk), C.byref(G), p(Wsc), None,
+                                                     0.05, 1.0, float(B), 0.0, None), 238 * 4),
+    }
+    for f, _ in kernels.values():    # warm: code objects loaded, caches in their steady state
+        for _ in range(3):
+            assert f() == 0
+    torch.cuda.synchronize()
+    phk.copy_(ph0)
+    seq = {"k_hidden": [(10, 11, "prologue (loads, class term, Philox)"), (11, 0, "to strip_mma entry"), (0, 1, "first LDS-DMA quads issued"),
+                        (1, 2, "first quad landed"), (2, 3, "MFMA loop"), (3, 4, "combine partial strips"), (4, 12, "epilogue"), (10, 12, "WAVE LIFETIME")],
+           "k_visible": [(10, 11, "prologue"), (0, 1, "first LDS-DMA quads issued"), (1, 2, "first quad landed"), (2, 3, "MFMA loop"),
+                         (3, 4, "combine partial strips"), (4, 12, "epilogue"), (10, 12, "WAVE LIFETIME")],
+           "k_grad": [(10, 11, "prologue"), (0, 1, "phase 0: LDS-DMA issued"), (1, 2, "phase 0: quad landed"), (2, 3, "phase 0: MFMA loop"),
+                      (3, 4, "phase 0: combine"), (5, 6, "phase 1: LDS-DMA issued"), (6, 7, "phase 1: quad landed"), (7, 8, "phase 1: MFMA loop"),
+                      (8, 9, "phase 1: combine"), (9, 12, "epilogue (W update)"), (10, 12, "WAVE LIFETIME")]}
+    for name, (f, _) in kernels.items():     # back-to-back launch time of the stamped build (stamps cost a few %)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(300):
+            f()
+        e1.record()
+        e1.synchronize()
+        print(f"{name}: {e0.elapsed_time(e1) / 300 * 1e3:.2f} us per launch (stamped build, back to back)")
+    for name, (f, n_waves) in kernels.items():
+        res = []
+        for rep in range(5):
+            lib.qbm_diag_clear_stamps()
+            assert f() == 0
+            torch.cuda.synchronize()
+            buf = np.zeros((n_waves, 16), np.uint64)
+            lib.qbm_diag_read_stamps(buf.ctypes.data_as(C.c_void_p), n_waves)
+            res.append(buf)
+        st = res[-1].astype(np.int64)
+        ok = (st[:, 10] != 0) & (st[:, 12] != 0) & (st[:, 0] != 0) & (st[:, 4] != 0)
+        if name == "k_grad":
+            ok &= st[:, 5] != 0           # kind-W workgroups (both contractions on the LDS-DMA path)
+        st = st[ok]
+        print(f"== {name}: {ok.sum()} stamped waves; first entry -> last exit {int(st[:, 12].max() - st[:, 10].min())} cycles; "
+              f"entry skew p90-p10 {int(np.percentile(st[:, 10], 90) - np.percentile(st[:, 10], 10))}")
+        for a, bb, what in seq[name]:
+            dts = (st[:, bb] - st[:, a]).astype(np.float64)
+            print(f"   {what:40s} median {np.median(dts):8.0f}   p10 {np.percentile(dts, 10):8.0f}   p90 {np.percentile(dts, 90):8.0f}")
+
+
+if __name__ == "__main__":
+    main()
