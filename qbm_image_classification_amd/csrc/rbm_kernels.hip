@@ -87,6 +87,10 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
     constexpr int MT = H_MT, NT = H_NT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     QBM_STAMP(10);
+    // every kernel argument in ONE round trip to the (cold) scalar cache: the compiler otherwise fetches them where they
+    // are first used, one dependent s_load latency after the other in front of the first operand transfer
+    asm volatile("" ::"s"(a.v), "s"(a.y), "s"(a.W), "s"(a.d), "s"(a.U), "s"(a.p), "s"(a.s), "s"(a.s8), "s"(a.B), "s"(a.V),
+                 "s"(a.H), "s"(a.C), "s"(a.KP), "s"(a.seed), "s"(a.offset), "s"(a.row0));
     const int nM = (a.B + 16 * MT - 1) / (16 * MT), nN = (a.H + 16 * NT - 1) / (16 * NT);
     int ms, ns;
     strip_coords(nM, nN, ms, ns);
@@ -305,6 +309,8 @@ __global__ __launch_bounds__(256) void k_visible(VisibleArgs a)
     }
     constexpr int MT = V_MT, NT = V_NT;
     QBM_STAMP(10);
+    asm volatile("" ::"s"(a.h), "s"(a.W), "s"(a.b), "s"(a.p), "s"(a.s), "s"(a.s8), "s"(a.B), "s"(a.V), "s"(a.H), "s"(a.KP),
+                 "s"(a.seed), "s"(a.offset), "s"(a.row0));   // all arguments in one scalar-cache round trip (see k_hidden)
     const int nM = (a.B + 16 * MT - 1) / (16 * MT), nN = (a.V + 16 * NT - 1) / (16 * NT);
     int ms, ns;
     strip_coords(nM, nN, ms, ns, a.n_aux);
@@ -574,6 +580,8 @@ __global__ __launch_bounds__(256) void k_grad(GradArgs a)
     constexpr int MT = G_MT, NT = G_NT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     QBM_STAMP(10);
+    asm volatile("" ::"s"(a.A0), "s"(a.P0), "s"(a.A1), "s"(a.P1), "s"(a.gW), "s"(a.W), "s"(a.B), "s"(a.V), "s"(a.H), "s"(a.C),
+                 "s"(a.KP), "s"(a.nU), "s"(a.nB), "s"(a.nC));   // the arguments of the W workgroups in one scalar-cache round trip
     int blk = blockIdx.x;
     const ViewCContig P0{a.P0, a.H, a.H, a.B}, P1{a.P1, a.H, a.H, a.B};
     const typename CView<T0>::type D0{reinterpret_cast<const T0*>(a.A0), a.V, a.V, a.B};

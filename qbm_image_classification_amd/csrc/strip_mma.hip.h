@@ -53,10 +53,7 @@ namespace qbm { constexpr int kStampWaves = 8192; static __device__ unsigned lon
 #ifndef QBM_DIAG_MODE
 #define QBM_DIAG_MODE 0
 #endif
-// 1: request every LDS-DMA transfer of a panel before its first MFMA; 0: two quads ahead of the MFMAs
-#ifndef QBM_DMA_ALL_UPFRONT
-#define QBM_DMA_ALL_UPFRONT 0
-#endif
+
 
 namespace qbm {
 
@@ -320,8 +317,9 @@ __device__ __forceinline__ void gload_b128(u32x4& dst, const void* p)
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
 
-// `pre` hook of strip_mma that does nothing
+// hook of strip_mma that does nothing
 struct NoPre {
+    __device__ __forceinline__ void operator()() const {}
     __device__ __forceinline__ void operator()(int) const {}
 };
 
@@ -347,15 +345,17 @@ __device__ __forceinline__ void vm_wait(int n)
 // KP: panel length, multiple of 64.  lds: the workgroup's dynamic LDS (strip_lds_bytes<MT,NT,sizeof(elem)>(KP)).
 // FAST_A / FAST_B: the operand is staged by LDS-DMA (the host guarantees alignment and whole 16-byte units);
 // otherwise its values go through registers (any shape, any alignment, synthesised operands).
-// pre(n): called ONCE by every wave, right after its first LDS-DMA transfers have been issued (n = how many vector-memory
-// instructions this wave has issued inside strip_mma until then; 0 on the register-staged path, where the hook runs
-// first).  It is the place for the caller's contraction-independent work (bias / class-term loads issued before the call
-// and consumed here behind vm_wait(n), the Philox draw): that work then runs while the first operand tiles are in flight
-// instead of in front of them.
-template <int MT, int NT, bool FAST_A, bool FAST_B, int CPT = 4, class AView, class BView, class Pre = NoPre>
+// Two hooks, each called ONCE by every wave, for the caller's contraction-independent work (bias / class-term loads, the
+// Philox draw), so that it runs while the first operand tiles are in flight instead of in front of them -- a kernel's
+// first transfers miss every cache and are what its start waits for, so they go out before anything else:
+//   pre0()  right after the transfers of the first quad have been issued: the place to ISSUE loads;
+//   pre(n)  right after those of the second quad (n = vector-memory instructions this wave has issued since pre0):
+//           the place for arithmetic, and for consuming pre0's loads behind vm_wait(n).
+// On the register-staged path both run first (n = 0).
+template <int MT, int NT, bool FAST_A, bool FAST_B, int CPT = 4, class AView, class BView, class Pre0 = NoPre, class Pre = NoPre>
 __device__ __forceinline__ StripOut<MT, NT, CPT> strip_mma(const AView& A, const BView& Bv, int m0, int n0, int K,
-                                                           char* __restrict__ lds, int KP, Pre&& pre = NoPre{},
-                                                           int stamp0 = 0)
+                                                           char* __restrict__ lds, int KP, Pre0&& pre0 = NoPre{},
+                                                           Pre&& pre = NoPre{}, int stamp0 = 0)
 {
     (void)stamp0;   // first stamp slot of this call (diagnostic builds only)
     using TA = typename AView::elem;
@@ -547,35 +547,6 @@ __device__ __forceinline__ StripOut<MT, NT, CPT> strip_mma(const AView& A, const
             const int quads = (pieces + 3) >> 2;
             auto quad_pieces = [&](int qd) { return min(4, pieces - 4 * qd); };
             auto quad_dmas = [&](int qd) { return qd < quads ? (A8 ? MT : MT * quad_pieces(qd)) + NT * quad_pieces(qd) : 0; };
-#ifdef QBM_HACK_FULL_LINES
-            // TIMING-ONLY experiment (wrong results): K-contiguous operands requested as 8 rows x 128 B per instruction
-            // instead of 16 rows x 64 B -- the same bytes, half the cache-line requests
-            auto issue_quad = [&](int qd) {
-                const int np = quad_pieces(qd);
-                if constexpr (A8 && A_K4) {
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) {
-                        const unsigned v = (unsigned)((m0 + 16 * i + (lane & 7) + 8 * (qd & 1)) * (int)A.ld + kb + 128 * (qd >> 1) + 16 * (lane >> 3));
-                        blds16(ra, v, imgA + i * a_tile + qd * 1024);
-                    }
-                }
-                for (int pc = 4 * qd; pc < 4 * qd + np; ++pc) {
-                    if constexpr (B_K4) {
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) {
-                            const unsigned v = (unsigned)(((n0 + 16 * t + (lane & 7) + 8 * (pc & 1)) * (int)Bv.ld + kb + 32 * (pc >> 1) + 4 * (lane >> 3)) * 4);
-                            blds16(rb, v, imgB + t * b_tile + pc * 1024);
-                        }
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) {
-                            blds16(rb, lb[t].voff, imgB + t * b_tile + pc * 1024);
-                            lb[t].voff += lb[t].step;
-                        }
-                    }
-                }
-            };
-#else
             auto issue_quad = [&](int qd) {
                 const int np = quad_pieces(qd);
                 if constexpr (A8) {
@@ -602,29 +573,11 @@ __device__ __forceinline__ StripOut<MT, NT, CPT> strip_mma(const AView& A, const
                     }
                 }
             };
-#endif
-#if QBM_DMA_ALL_UPFRONT
-            // every transfer of the panel is requested before the first MFMA (the panel's LDS image holds all of it, and
-            // strip_max_panel keeps the request count inside the vmcnt range): no LDS-DMA issue -- which blocks the wave while
-            // the memory pipeline is full -- sits between the MFMAs; the wait before quad qd leaves the later quads in flight
-            int pend = 0;
-            for (int j = 0; j < quads; ++j) { issue_quad(j); pend += quad_dmas(j); }
+            if (qbm_diag != 4 && quads > 0) issue_quad(0);
+            if (kb == kq0) pre0();
+            if (qbm_diag != 4 && quads > 1) issue_quad(1);
             QBM_STAMP(stamp0 + 1);
-            if (kb == kq0) pre(pend);
-            for (int qd = 0; qd < quads; ++qd) {
-                pend -= quad_dmas(qd);
-                vm_wait(pend);
-                if (qd == 0) QBM_STAMP(stamp0 + 2);
-                if (quad_pieces(qd) == 4) run_quad_n(std::integral_constant<int, 4>{}, qd);
-                else run_quad(qd, quad_pieces(qd));
-            }
-#else
-            if (qbm_diag != 4) {
-                if (quads > 0) issue_quad(0);
-                if (quads > 1) issue_quad(1);
-            }
-            QBM_STAMP(stamp0 + 1);
-            if (kb == kq0) pre(quad_dmas(0) + quad_dmas(1));
+            if (kb == kq0) pre(quad_dmas(1));
             // Full quads run in one loop body (one code path: the accumulators stay in place); the wait before quad qd
             // leaves the transfers of quads qd+1, qd+2 in flight, counted with constants (a full quad is kFull DMA
             // instructions; the tail quad is counted as none, which only waits a little longer than necessary).
@@ -648,10 +601,9 @@ __device__ __forceinline__ StripOut<MT, NT, CPT> strip_mma(const AView& A, const
                 if (qd == 0) QBM_STAMP(stamp0 + 2);
                 if (qbm_diag != 3) run_quad(qd, pieces - 4 * qd);
             }
-#endif
         } else {
             // ---- at least one operand goes through registers (unaligned / ragged / synthesised)
-            if (kb == kq0) pre(0);
+            if (kb == kq0) { pre0(); pre(0); }
             const int quads = (pieces + 3) >> 2;
             if constexpr (FAST_A) {
                 const rsrc_t ra = A.rsrc();
