@@ -563,6 +563,7 @@ struct GradArgs {
     int nU, nB, nC;                              // workgroups of kind U, B, C (they precede kind W)
     bool vecO;
     const float* gUsub;                          // non-null: class-weight gradient = (phase0 - phase1) - gUsub
+    int lds_group;                               // bytes of one group's LDS staging region
 };
 
 __device__ __forceinline__ float upd(float th, float g, const GradArgs& a, bool sparse)
@@ -574,23 +575,67 @@ __device__ __forceinline__ float upd(float th, float g, const GradArgs& a, bool 
     return sparse ? th - a.sparse : th;
 }
 
-template <class T0, class T1, bool FAST>
-__global__ __launch_bounds__(256) void k_grad(GradArgs a)
+// The two phases of a gradient block are contracted SIDE BY SIDE by a 512-thread workgroup: threads 0..255 ("group 0",
+// wavefronts 0..3 = K quarters of phase 0) and threads 256..511 (group 1, phase 1), each with an LDS staging region of
+// its own.  Two wavefronts per SIMD: while one is parked on its operand transfers or an LDS read, the other issues MFMAs
+// (one after the other, the phases left the MFMA pipe idle for more than half of the kernel).  The groups then swap their
+// strips through LDS and share the epilogue.  Same arithmetic as phase after phase: g = o0 - o1 of the same two [Q] sums.
+template <int MT_, int NT_>
+__device__ __forceinline__ void swap_strips(const StripOut<MT_, NT_>& mine, int grp, char* lds_all, StripOut<MT_, NT_>& o0,
+                                            StripOut<MT_, NT_>& o1)
+{
+    constexpr int NP = StripOut<MT_, NT_>::NP;
+    const int t = threadIdx.x & 255;
+    float4* x = reinterpret_cast<float4*>(lds_all);   // every thread has left strip_mma: the staging regions are free
+#pragma unroll
+    for (int p = 0; p < NP; ++p) x[(grp * NP + p) * 256 + t] = mine.sum[p];
+    __syncthreads();
+    const bool first = grp == 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const float4 other = x[((1 - grp) * NP + p) * 256 + t];
+        const float4 own = mine.sum[p];
+        o0.sum[p] = make_float4(first ? own.x : other.x, first ? own.y : other.y, first ? own.z : other.z, first ? own.w : other.w);
+        o1.sum[p] = make_float4(first ? other.x : own.x, first ? other.y : own.y, first ? other.z : own.z, first ? other.w : own.w);
+    }
+}
+
+// PAR (both data operands uint8: the Gibbs states of the CD-k / PCD step): 512 threads, the phases side by side.
+// Otherwise (fp32 data: twice the staging bytes, two regions do not fit the LDS): 256 threads, phase after phase.
+template <class T0, class T1, bool FAST, bool PAR>
+__global__ __launch_bounds__(PAR ? 512 : 256) void k_grad(GradArgs a)
 {
     constexpr int MT = G_MT, NT = G_NT;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
+    extern __shared__ __attribute__((aligned(16))) char lds_all[];
     QBM_STAMP(10);
     asm volatile("" ::"s"(a.A0), "s"(a.P0), "s"(a.A1), "s"(a.P1), "s"(a.gW), "s"(a.W), "s"(a.B), "s"(a.V), "s"(a.H), "s"(a.C),
-                 "s"(a.KP), "s"(a.nU), "s"(a.nB), "s"(a.nC));   // the arguments of the W workgroups in one scalar-cache round trip
+                 "s"(a.KP), "s"(a.nU), "s"(a.nB), "s"(a.nC), "s"(a.lds_group));   // the arguments of the W workgroups in one scalar-cache round trip
+    const int grp = PAR ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;   // 0: phase-0 operands, 1: phase-1 operands
+    char* lds = lds_all + (size_t)grp * a.lds_group;
     int blk = blockIdx.x;
     const ViewCContig P0{a.P0, a.H, a.H, a.B}, P1{a.P1, a.H, a.H, a.B};
     const typename CView<T0>::type D0{reinterpret_cast<const T0*>(a.A0), a.V, a.V, a.B};
     const typename CView<T1>::type D1{reinterpret_cast<const T1*>(a.A1), a.V, a.V, a.B};
+    // both phases of one gradient block: o0, o1 as every finishing thread needs them (PAR: only group 0 finishes the
+    // small blocks, group 1 leaves)
+#define QBM_TWO_PHASES(SOT, CALL0, CALL1)        \
+    SOT o0, o1;                                  \
+    if constexpr (PAR) {                         \
+        SOT mine;                                \
+        if (grp == 0) mine = CALL0;              \
+        else mine = CALL1;                       \
+        swap_strips(mine, grp, lds_all, o0, o1); \
+        if (grp != 0) return;                    \
+    } else {                                     \
+        o0 = CALL0;                              \
+        o1 = CALL1;                              \
+    }
     if (blk < a.nU) {  // class-weight rows and the hidden-bias row (C + 1 <= 16 rows: one row tile) x 16*NT hidden columns
         const int n0 = blk * 16 * NT;
         const ViewAugY Y0{a.Y0, a.C}, Y1{a.Y1, a.C};
-        const auto o0 = strip_mma<1, NT, false, FAST>(Y0, P0, 0, n0, a.B, lds, a.KP);
-        const auto o1 = strip_mma<1, NT, false, FAST>(Y1, P1, 0, n0, a.B, lds, a.KP);
+        using SOT = StripOut<1, NT>;
+        QBM_TWO_PHASES(SOT, (strip_mma<1, NT, false, FAST>(Y0, P0, 0, n0, a.B, lds, a.KP)),
+                       (strip_mma<1, NT, false, FAST>(Y1, P1, 0, n0, a.B, lds, a.KP)))
 #pragma unroll
         for (int op = 0; op < o0.NP; ++op) {
             if (!o0.valid(op) || o0.row(op) > a.C) continue;
@@ -617,8 +662,9 @@ __global__ __launch_bounds__(256) void k_grad(GradArgs a)
     if (blk < a.nB) {  // visible bias: column sums of the data = data^T . ones, 16*MT visible units per workgroup
         const int m0 = blk * 16 * MT;
         const ViewOnesCol ones;
-        const auto o0 = strip_mma<MT, 1, FAST, false>(D0, ones, m0, 0, a.B, lds, a.KP);
-        const auto o1 = strip_mma<MT, 1, FAST, false>(D1, ones, m0, 0, a.B, lds, a.KP);
+        using SOT = StripOut<MT, 1>;
+        QBM_TWO_PHASES(SOT, (strip_mma<MT, 1, FAST, false>(D0, ones, m0, 0, a.B, lds, a.KP)),
+                       (strip_mma<MT, 1, FAST, false>(D1, ones, m0, 0, a.B, lds, a.KP)))
 #pragma unroll
         for (int op = 0; op < o0.NP; ++op) {
             if (!o0.valid(op) || o0.cg(op) != 0) continue;
@@ -635,8 +681,9 @@ __global__ __launch_bounds__(256) void k_grad(GradArgs a)
         const int n0 = blk * 16 * NT;
         const ViewOnesRow ones;
         const ViewCContig Y0{a.Y0, a.C, a.C, a.B}, Y1{a.Y1, a.C, a.C, a.B};
-        const auto o0 = strip_mma<1, NT, false, false>(ones, Y0, 0, n0, a.B, lds, a.KP);
-        const auto o1 = strip_mma<1, NT, false, false>(ones, Y1, 0, n0, a.B, lds, a.KP);
+        using SOT = StripOut<1, NT>;
+        QBM_TWO_PHASES(SOT, (strip_mma<1, NT, false, false>(ones, Y0, 0, n0, a.B, lds, a.KP)),
+                       (strip_mma<1, NT, false, false>(ones, Y1, 0, n0, a.B, lds, a.KP)))
 #pragma unroll
         for (int op = 0; op < o0.NP; ++op) {
             if (!o0.valid(op) || o0.row(op) != 0) continue;
@@ -651,46 +698,65 @@ __global__ __launch_bounds__(256) void k_grad(GradArgs a)
         }
         return;
     }
+#undef QBM_TWO_PHASES
     const int nM = (a.V + 16 * MT - 1) / (16 * MT), nN = (a.H + 16 * NT - 1) / (16 * NT);
     int ms, ns;
     strip_coords(nM, nN, ms, ns, a.nU + a.nB + a.nC);
     const int m0 = ms * 16 * MT, n0 = ns * 16 * NT;
-    // fused update: the W tile is requested behind the first operand transfers and consumed in the epilogue
     using SO = StripOut<MT, NT>;
-    float4 w_old[SO::NP];
-    auto pre0 = [&]() {
-#pragma unroll
-        for (int op = 0; op < SO::NP; ++op) {
-            const int m = min(m0 + SO::row(op), a.V - 1), nb = n0 + 4 * SO::cg(op);
-            w_old[op] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.W && a.vecO && nb + 3 < a.H) w_old[op] = *reinterpret_cast<const float4*>(a.W + (long)m * a.H + nb);
-        }
-    };
-    QBM_STAMP(11);
-    const auto o0 = strip_mma<MT, NT, FAST, FAST>(D0, P0, m0, n0, a.B, lds, a.KP, pre0);
-    const auto o1 = strip_mma<MT, NT, FAST, FAST>(D1, P1, m0, n0, a.B, lds, a.KP, NoPre{}, NoPre{}, 5);
-#pragma unroll
-    for (int op = 0; op < o0.NP; ++op) {
-        if (!o0.valid(op)) continue;
-        const int m = m0 + o0.row(op), nb = n0 + 4 * o0.cg(op);
-        if (m >= a.V || nb >= a.H) continue;
-        const float g[4] = {o0.sum[op].x - o1.sum[op].x, o0.sum[op].y - o1.sum[op].y, o0.sum[op].z - o1.sum[op].z,
-                            o0.sum[op].w - o1.sum[op].w};
+    static_assert(SO::NP == 2, "PAR: the two groups share the epilogue, output 0 of every thread to group 0, output 1 to group 1");
+    // one output of the strip: gradient, and the fused update on the W tile `w` requested before the contraction
+    auto finish = [&](int op, const float4& s0, const float4& s1, const float4& w_old) {
+        const int m = m0 + SO::row(op), nb = n0 + 4 * SO::cg(op);
+        if (!SO::valid(op) || m >= a.V || nb >= a.H) return;
+        const float g[4] = {s0.x - s1.x, s0.y - s1.y, s0.z - s1.z, s0.w - s1.w};
         const long off = (long)m * a.H + nb;
-        if (nb + 3 < a.H && a.vecO) {
+        if (a.vecO && nb + 3 < a.H) {
             if (a.gW) *reinterpret_cast<float4*>(a.gW + off) = make_float4(g[0], g[1], g[2], g[3]);
             if (a.W) {
-                float4 w = w_old[op];
+                float4 w = w_old;
                 w.x = upd(w.x, g[0], a, false); w.y = upd(w.y, g[1], a, false);
                 w.z = upd(w.z, g[2], a, false); w.w = upd(w.w, g[3], a, false);
                 *reinterpret_cast<float4*>(a.W + off) = w;
             }
-            continue;
+            return;
         }
         for (int e = 0; e < 4 && nb + e < a.H; ++e) {
             if (a.gW) a.gW[off + e] = g[e];
             if (a.W) a.W[off + e] = upd(a.W[off + e], g[e], a, false);
         }
+    };
+    auto w_tile = [&](int op) {   // fused update: the W tile of output `op` (requested behind the first operand transfers)
+        const int m = min(m0 + SO::row(op), a.V - 1), nb = n0 + 4 * SO::cg(op);
+        return (a.W && a.vecO && nb + 3 < a.H) ? *reinterpret_cast<const float4*>(a.W + (long)m * a.H + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    if constexpr (PAR) {
+        // group 0 finishes output 0 and needs phase 1's output 0; group 1 finishes output 1 and needs phase 0's output 1
+        const bool first = grp == 0;
+        float4 w_old = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto pre0 = [&]() { w_old = first ? w_tile(0) : w_tile(1); };
+        QBM_STAMP(11);
+        SO mine;
+        if (first) mine = strip_mma<MT, NT, FAST, FAST>(D0, P0, m0, n0, a.B, lds, a.KP, pre0);
+        else mine = strip_mma<MT, NT, FAST, FAST>(D1, P1, m0, n0, a.B, lds, a.KP, pre0, NoPre{}, 5);
+        const float4 keep = first ? mine.sum[0] : mine.sum[1], give = first ? mine.sum[1] : mine.sum[0];
+        float4* x = reinterpret_cast<float4*>(lds_all);   // every thread has left strip_mma: the staging regions are free
+        x[grp * 256 + ((int)threadIdx.x & 255)] = give;
+        __syncthreads();
+        const float4 got = x[(1 - grp) * 256 + ((int)threadIdx.x & 255)];
+        if (first) finish(0, keep, got, w_old);
+        else finish(1, got, keep, w_old);
+    } else {
+        float4 w_old[SO::NP];
+        auto pre0 = [&]() {
+#pragma unroll
+            for (int op = 0; op < SO::NP; ++op) w_old[op] = w_tile(op);
+        };
+        QBM_STAMP(11);
+        const SO o0 = strip_mma<MT, NT, FAST, FAST>(D0, P0, m0, n0, a.B, lds, a.KP, pre0);
+        const SO o1 = strip_mma<MT, NT, FAST, FAST>(D1, P1, m0, n0, a.B, lds, a.KP, NoPre{}, NoPre{}, 5);
+#pragma unroll
+        for (int op = 0; op < SO::NP; ++op) finish(op, o0.sum[op], o1.sum[op], w_old[op]);
     }
     QBM_STAMP(12);
 }
@@ -895,17 +961,33 @@ int launch_grad_t(int V, int H, int C, int B, const void* A0, const float* Y0, c
                aux_fused ? aux_fused->U : nullptr, aux_fused ? aux_fused->c : nullptr,
                lr, factor, bs, sparse, B, V, H, C, panel_for<MT, NT, 4>(B),
                nN, want_b ? nM : 0, want_c ? (C + 16 * NT - 1) / (16 * NT) : 0,
-               (H % 4 == 0) && (!G->gW || aligned16(G->gW)) && (!W_fused || aligned16(W_fused)), gU_sub};
+               (H % 4 == 0) && (!G->gW || aligned16(G->gW)) && (!W_fused || aligned16(W_fused)), gU_sub, 0};
     const bool fast = (B % 16 == 0) && (V % 16 == 0) && (H % 4 == 0) && aligned16(A0) && aligned16(A1) && aligned16(P0) &&
                       aligned16(P1) && small2g((long)B * V, 4) && small2g((long)B * H, 4);
     const int grid = a.nU + a.nB + a.nC + nM * nN;
-    const size_t lds = strip_lds_bytes<MT, NT, 4>(a.KP);  // the fp32 synthesised operands (kinds U, B, C) set the budget
-    if (fast) {
-        if (int rc = set_lds(k_grad<T0, T1, true>, lds)) return rc;
-        hipLaunchKernelGGL((k_grad<T0, T1, true>), dim3(grid), dim3(256), lds, st, a);
+    constexpr bool PAR = sizeof(T0) == 1 && sizeof(T1) == 1;
+    size_t lds;
+    if constexpr (PAR) {
+        // one staging region per phase group, sized for the largest of the four kinds of workgroup (uint8 data; the class
+        // rows / ones operands of kinds U, C are synthesised fp32 single-tile operands); the strips the groups swap
+        // afterwards (2 x NP float4 per thread of a group) must fit as well
+        size_t g = strip_lds_bytes<MT, NT, 1>(a.KP);
+        if (g < (size_t)strip_lds_bytes<1, NT, 4>(a.KP)) g = strip_lds_bytes<1, NT, 4>(a.KP);
+        if (g < (size_t)strip_lds_bytes<MT, 1, 1>(a.KP)) g = strip_lds_bytes<MT, 1, 1>(a.KP);
+        a.lds_group = (int)g;
+        lds = 2 * g;
+        const size_t swap_bytes = 2 * StripOut<MT, NT>::NP * 256 * sizeof(float4);
+        if (lds < swap_bytes) lds = swap_bytes;
+        if (lds > 163840) return fail(QBM_ERR_ARG, "two_phase_grad: LDS budget exceeded");
     } else {
-        if (int rc = set_lds(k_grad<T0, T1, false>, lds)) return rc;
-        hipLaunchKernelGGL((k_grad<T0, T1, false>), dim3(grid), dim3(256), lds, st, a);
+        lds = strip_lds_bytes<MT, NT, 4>(a.KP);  // the fp32 operands set the budget
+    }
+    if (fast) {
+        if (int rc = set_lds(k_grad<T0, T1, true, PAR>, lds)) return rc;
+        hipLaunchKernelGGL((k_grad<T0, T1, true, PAR>), dim3(grid), dim3(PAR ? 512 : 256), lds, st, a);
+    } else {
+        if (int rc = set_lds(k_grad<T0, T1, false, PAR>, lds)) return rc;
+        hipLaunchKernelGGL((k_grad<T0, T1, false, PAR>), dim3(grid), dim3(PAR ? 512 : 256), lds, st, a);
     }
     QBM_CHECK_LAUNCH("k_grad");
     return QBM_OK;

@@ -296,9 +296,10 @@ struct StripOut {
     static constexpr int kCG = 16 * NT / CPT;                       // column groups per strip row
     static constexpr int NP = (16 * MT * kCG + 255) / 256;
     float4 sum[NP];
-    __device__ __forceinline__ static bool valid(int p) { return (int)threadIdx.x + 256 * p < 16 * MT * kCG; }
-    __device__ __forceinline__ static int row(int p) { return ((int)threadIdx.x + 256 * p) / kCG; }
-    __device__ __forceinline__ static int cg(int p) { return ((int)threadIdx.x + 256 * p) % kCG; }
+    // (threadIdx.x & 255: a 512-thread workgroup is two groups of 256 threads, each running a contraction of its own)
+    __device__ __forceinline__ static bool valid(int p) { return ((int)threadIdx.x & 255) + 256 * p < 16 * MT * kCG; }
+    __device__ __forceinline__ static int row(int p) { return (((int)threadIdx.x & 255) + 256 * p) / kCG; }
+    __device__ __forceinline__ static int cg(int p) { return (((int)threadIdx.x & 255) + 256 * p) % kCG; }
 };
 
 // Loads whose consumer sits behind an explicit vm_wait(): the compiler's wait-count pass does not see them, so it
@@ -364,7 +365,7 @@ __device__ __forceinline__ StripOut<MT, NT, CPT> strip_mma(const AView& A, const
     constexpr bool A_K4 = AView::kK4, B_K4 = BView::kK4;
     constexpr int ASZ = (int)sizeof(TA);
     static_assert(sizeof(typename BView::elem) == 4, "the B operand is fp32");
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x & 255;   // the thread's index inside its group of four wavefronts
     const int lane = tid & 63;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave id == K quarter (wave-uniform, SGPR)
     const int Kq = quarter_len(K);
