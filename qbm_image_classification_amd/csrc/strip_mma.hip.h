@@ -23,7 +23,10 @@
 //   fp32 "lin" image (M/N contiguous):          dword k*16 + r -> fragment dword s*64 + lane
 //   u8   "k4"  image: 16-byte slot piece*16 + r = 16 consecutive k of one row -> one ds_read_b128 per
 //               piece, byte (lane>>4) of dword s is k-step s
-//   u8   "lin" image: 16-byte slot k = 16 consecutive m -> ds_read_u8 at (4s + (lane>>4))*16 + (lane&15)
+//   u8   "lin" image: 16-byte slot k*MT + tile = 16 consecutive m of one row tile (the MT row tiles of a strip are
+//               adjacent in memory, so ONE transfer instruction covers 64/MT k for all of them with 16*MT-byte segments:
+//               a quarter of the cache-line requests of a tile-by-tile transfer at MT = 4)
+//               -> ds_read_u8 at ((4s + (lane>>4))*MT + tile)*16 + (lane&15)
 // A "piece" is 16 consecutive k (4 MFMA k-steps).  Out-of-range k / rows are staged as zeros from a
 // 16-byte zero page, so the MFMA loop needs no masks (fmaf(0, b, acc) == acc).
 #pragma once
@@ -203,6 +206,14 @@ struct ViewCContigU8 {
         const int k = kb + lane;
         return DmaLane{c0 < cols ? (unsigned)(k * (int)ld + c0) : kOOB, (unsigned)(64 * ld), k, 64};
     }
+    // transfer instruction j (0..TILES-1) of a quad, all TILES adjacent 16-wide tiles from column c0 on: lane L takes
+    // k = kb + (64/TILES)*j + L/TILES of tile L % TILES
+    template <int TILES>
+    __device__ __forceinline__ DmaLane lane0_tiles(int c0, int kb, int lane, int j) const
+    {
+        const int k = kb + (64 / TILES) * j + lane / TILES, c = c0 + 16 * (lane % TILES);
+        return DmaLane{c < cols ? (unsigned)(k * (int)ld + c) : kOOB, (unsigned)(64 * ld), k, 64};
+    }
     __device__ __forceinline__ uint4 get(int c0, int kb, int kend, int slot) const
     {
         const int k = kb + slot;
@@ -375,7 +386,9 @@ __device__ __forceinline__ StripOut<MT, NT, CPT> strip_mma(const AView& A, const
     char* img = lds + (size_t)q * wave_bytes;
     char* imgA = img;                              // MT tiles of 16*KP*ASZ bytes
     char* imgB = img + (size_t)MT * 16 * KP * ASZ;  // NT tiles of 16*KP*4 bytes
-    const int a_tile = 16 * KP * ASZ, b_tile = 16 * KP * 4;
+    // u8 "lin" A image: the MT row tiles interleaved per k (see the header); every other image: one region per tile
+    constexpr bool A_TILES = A8 && !A_K4;
+    const int a_tile = A_TILES ? 16 : 16 * KP * ASZ, b_tile = 16 * KP * 4;
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -385,7 +398,7 @@ __device__ __forceinline__ StripOut<MT, NT, CPT> strip_mma(const AView& A, const
     QBM_STAMP(stamp0 + 0);
 
     const int fragB = (B_K4 ? ((lane & 15) * 4 + (lane >> 4)) : lane) * 4;                  // byte offset in a piece
-    const int fragA = A8 ? (A_K4 ? (lane & 15) * 16 + (lane >> 4) : (lane >> 4) * 16 + (lane & 15))  // u8: see header
+    const int fragA = A8 ? (A_K4 ? (lane & 15) * 16 + (lane >> 4) : (lane >> 4) * 16 * MT + (lane & 15))  // u8: see header
                          : (A_K4 ? ((lane & 15) * 4 + (lane >> 4)) : lane) * 4;
 
     // ---- MFMA loop over one "quad" (up to 4 pieces = 64 k).
@@ -400,7 +413,7 @@ __device__ __forceinline__ StripOut<MT, NT, CPT> strip_mma(const AView& A, const
     constexpr int kReadsA = A8 ? 4 : 2, kReadsB = 2;
     constexpr int MT1 = (15 - kReadsB * NT) / kReadsA < MT ? (15 - kReadsB * NT) / kReadsA : MT;  // tiles in chunk 1
     constexpr int kChunk1 = kReadsB * NT + kReadsA * MT1;   // <= 15 = the largest lgkmcnt
-    constexpr int kPieceA = A8 ? 256 : 1024;
+    constexpr int kPieceA = A8 ? (A_TILES ? 256 * MT : 256) : 1024;   // bytes from piece to piece at one tile's base address
     struct Frag {
         u32x2 a2[MT][2];     // fp32: k-steps (0,1) and (2,3)
         uint32_t a1[MT][4];  // u8: one zero-extended byte per k-step
@@ -414,11 +427,11 @@ __device__ __forceinline__ StripOut<MT, NT, CPT> strip_mma(const AView& A, const
         return;
 #endif
         if constexpr (A8) {
-            constexpr int st = A_K4 ? 4 : 64;   // k4 image: byte 4s+g of the row; lin image: 16-byte slot 4s+g
-            asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(f.a1[i][0]) : "v"(ad), "n"(pc * 256) : "memory");
-            asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(f.a1[i][1]) : "v"(ad), "n"(pc * 256 + st) : "memory");
-            asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(f.a1[i][2]) : "v"(ad), "n"(pc * 256 + 2 * st) : "memory");
-            asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(f.a1[i][3]) : "v"(ad), "n"(pc * 256 + 3 * st) : "memory");
+            constexpr int st = A_K4 ? 4 : 64 * MT;   // k4 image: byte 4s+g of the row; lin image: 16-byte slot (4s+g)*MT + tile
+            asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(f.a1[i][0]) : "v"(ad), "n"(pc * kPieceA) : "memory");
+            asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(f.a1[i][1]) : "v"(ad), "n"(pc * kPieceA + st) : "memory");
+            asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(f.a1[i][2]) : "v"(ad), "n"(pc * kPieceA + 2 * st) : "memory");
+            asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(f.a1[i][3]) : "v"(ad), "n"(pc * kPieceA + 3 * st) : "memory");
         } else {
             asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(f.a2[i][0]) : "v"(ad), "n"(4 * pc), "n"(4 * pc + 1) : "memory");
             asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(f.a2[i][1]) : "v"(ad), "n"(4 * pc + 2), "n"(4 * pc + 3) : "memory");
@@ -542,7 +555,10 @@ __device__ __forceinline__ StripOut<MT, NT, CPT> strip_mma(const AView& A, const
             const rsrc_t ra = A.rsrc(), rb = Bv.rsrc();
             DmaLane la[MT], lb[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) la[i] = A.lane0(m0 + 16 * i, kb, lane);
+            for (int i = 0; i < MT; ++i) {
+                if constexpr (A_TILES) la[i] = A.template lane0_tiles<MT>(m0, kb, lane, i);   // instruction i of a quad
+                else la[i] = A.lane0(m0 + 16 * i, kb, lane);
+            }
 #pragma unroll
             for (int t = 0; t < NT; ++t) lb[t] = Bv.lane0(n0 + 16 * t, kb, lane);
             const int quads = (pieces + 3) >> 2;
@@ -553,8 +569,9 @@ __device__ __forceinline__ StripOut<MT, NT, CPT> strip_mma(const AView& A, const
                 if constexpr (A8) {
 #pragma unroll
                     for (int i = 0; i < MT; ++i) {
-                        // u8: one instruction covers the 4 pieces; lanes past the end of the K quarter read zeros
-                        blds16(ra, la[i].k < kend ? la[i].voff : kOOB, imgA + i * a_tile + qd * 1024);
+                        // u8: one instruction covers the 4 pieces (k4 image: of its tile; lin image: a (64/MT)-k slice of
+                        // every tile); lanes past the end of the K quarter read zeros
+                        blds16(ra, la[i].k < kend ? la[i].voff : kOOB, imgA + (A_TILES ? (qd * MT + i) * 1024 : i * a_tile + qd * 1024));
                         la[i].voff += la[i].step;
                         la[i].k += la[i].kstep;
                     }
@@ -610,9 +627,11 @@ __device__ __forceinline__ StripOut<MT, NT, CPT> strip_mma(const AView& A, const
                 const rsrc_t ra = A.rsrc();
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    DmaLane la = A.lane0(m0 + 16 * i, kb, lane);
+                    DmaLane la;
+                    if constexpr (A_TILES) la = A.template lane0_tiles<MT>(m0, kb, lane, i);
+                    else la = A.lane0(m0 + 16 * i, kb, lane);
                     for (int g = 0; g < (A8 ? quads : pieces); ++g) {
-                        blds16(ra, (!A8 || la.k < kend) ? la.voff : kOOB, imgA + i * a_tile + g * 1024);
+                        blds16(ra, (!A8 || la.k < kend) ? la.voff : kOOB, imgA + (A_TILES ? (g * MT + i) * 1024 : i * a_tile + g * 1024));
                         la.voff += la.step;
                         la.k += la.kstep;
                     }
@@ -620,8 +639,11 @@ __device__ __forceinline__ StripOut<MT, NT, CPT> strip_mma(const AView& A, const
             } else if constexpr (A8) {
                 for (int g = 0; g < quads; ++g)
 #pragma unroll
-                    for (int i = 0; i < MT; ++i)
-                        reinterpret_cast<uint4*>(imgA + i * a_tile)[g * 64 + lane] = A.get(m0 + 16 * i, kb, kend, g * 64 + lane);
+                    for (int i = 0; i < MT; ++i) {
+                        const uint4 v = A.get(m0 + 16 * i, kb, kend, g * 64 + lane);
+                        if constexpr (A_TILES) reinterpret_cast<uint4*>(imgA)[(g * 64 + lane) * MT + i] = v;   // slot k*MT + tile
+                        else reinterpret_cast<uint4*>(imgA + i * a_tile)[g * 64 + lane] = v;
+                    }
             } else {
                 for (int pc = 0; pc < pieces; ++pc)
 #pragma unroll
