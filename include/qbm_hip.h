@@ -152,7 +152,8 @@ typedef struct {
  * src/ClassificationRBM.py:19, :179-182).  v0[B,V] fp32 or uint8 (v0_dtype), y0[B,C] fp32.
  * Draw ids: h_0 -> offset; t = 1..k: v_t -> offset+3t-2, y_t -> offset+3t-1, h_t -> offset+3t.
  * chain_v (uint8 [B,V]) / chain_y (fp32 [B,C]) non-NULL = persistent chains (PCD): the negative chain
- * starts from them and they receive (v_k, y_k). */
+ * starts from them and the k-th Gibbs iteration writes (v_k, y_k) straight into them; ws->vk / ws->yk then hold
+ * the states of iteration k-1 (untouched for k = 1). */
 QBM_API int qbm_rbm_cd_chain(const qbm_rbm_params* P, const void* v0, int v0_dtype, const float* y0, int B, int k,
                              uint64_t seed, uint64_t offset, uint32_t row0, uint8_t* chain_v, float* chain_y,
                              const qbm_rbm_cd_workspace* ws, void* stream);

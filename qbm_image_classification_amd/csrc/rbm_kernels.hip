@@ -1161,16 +1161,13 @@ int qbm_rbm_cd_chain(const qbm_rbm_params* P, const void* v0, int v0_dtype, cons
     }
     for (int t = 1; t <= k; ++t) {
         const uint64_t o = offset + 3ull * (uint64_t)t;
+        // PCD: the last iteration writes (v_k, y_k) straight into the persistent chains (no copy afterwards)
+        uint8_t* v_out = (chain_v && t == k) ? chain_v : ws->vk;
+        float* y_out = (chain_v && t == k) ? chain_y : ws->yk;
         // v_t and y_t both depend on h_{t-1} only: one launch (class conditional as aux workgroups)
-        if (int rc = launch_visible(P, ws->h, QBM_U8, B, nullptr, nullptr, ws->vk, nullptr, ws->yk, seed, o - 2, o - 1, row0, st))
+        if (int rc = launch_visible(P, ws->h, QBM_U8, B, nullptr, nullptr, v_out, nullptr, y_out, seed, o - 2, o - 1, row0, st))
             return rc;
-        if (int rc = launch_hidden(P, ws->vk, QBM_U8, ws->yk, B, ws->phk, nullptr, ws->h, 0, seed, o, row0, st)) return rc;
-    }
-    if (chain_v) {
-        hipError_t e = hipMemcpyAsync(chain_v, ws->vk, (size_t)B * P->V, hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(chain_v)");
-        e = hipMemcpyAsync(chain_y, ws->yk, sizeof(float) * (size_t)B * P->C, hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(chain_y)");
+        if (int rc = launch_hidden(P, v_out, QBM_U8, y_out, B, ws->phk, nullptr, ws->h, 0, seed, o, row0, st)) return rc;
     }
     return QBM_OK;
 }
@@ -1188,9 +1185,10 @@ int qbm_rbm_cd_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void*
     if (!(batch_size > 0.f)) return fail(QBM_ERR_ARG, "cd_step: batch_size must be positive");
     qbm_rbm_grads g = *G;
     if (fuse_update) g.gW = nullptr;  // the whole update happens inside the gradient launch
-    return launch_grad(P->V, P->H, P->C, B, v0, v0_dtype, y0, ws->ph0, ws->vk, QBM_U8, ws->yk, ws->phk, &g,
-                       fuse_update ? P->W : nullptr, fuse_update ? P : nullptr, lr, factor, batch_size, sparse_constant,
-                       (hipStream_t)stream);
+    // PCD: (v_k, y_k) live in the persistent chains
+    return launch_grad(P->V, P->H, P->C, B, v0, v0_dtype, y0, ws->ph0, chain_v ? chain_v : ws->vk, QBM_U8,
+                       chain_v ? chain_y : ws->yk, ws->phk, &g, fuse_update ? P->W : nullptr, fuse_update ? P : nullptr, lr,
+                       factor, batch_size, sparse_constant, (hipStream_t)stream);
 }
 
 int qbm_rbm_disc_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const float* x, const int32_t* labels, int B,

@@ -195,7 +195,7 @@ class HipRbmOps:
                 batch_size, sparse, ws=None):
         """CD-k / PCD step: chain + gradient (+ fused update when `fuse`).
         v0: fp32 or uint8 {0,1} [B,V]; chain_v: uint8 [B,V] persistent state (PCD) or None.
-        -> workspace (ph0 f32, h u8, vk u8, yk f32, phk f32)"""
+        -> (ph0 f32, h u8, vk u8, yk f32, phk f32); with persistent chains (v_k, y_k) ARE chain_v / chain_y."""
         v0, vd = _state(v0, self.device)
         y0 = _f32(y0, self.device)
         B = v0.shape[0]
@@ -208,6 +208,8 @@ class HipRbmOps:
         check(self.lib.qbm_rbm_cd_step(C.byref(ps), C.byref(gs), ptr(v0), vd, ptr(y0), B, k, seed, offset, row0,
                                        ptr(chain_v), ptr(chain_y), C.byref(cws), int(fuse), lr, factor, batch_size,
                                        sparse, current_stream()), "qbm_rbm_cd_step")
+        if chain_v is not None:   # PCD: the k-th iteration wrote straight into the chains
+            return (ws[0], ws[1], chain_v, chain_y, ws[4])
         return ws
 
     def cd_workspace(self, P: ParamSet, B):

@@ -54,7 +54,7 @@ def main():
         if name.startswith("qbm_rbm_"):       # this library holds the rbm_kernels.hip translation unit only
             getattr(lib, name).argtypes = argtypes
     lib.qbm_diag_read_stamps.argtypes = [C.c_void_p, C.c_int]
-    V, H, NC, B = 784, 512, 10, 256
+    V, H, NC, B = 784, 512, 10, int(os.environ.get("QBM_STAMP_B", 256))
     dev = torch.device("cuda:0")
     torch.manual_seed(42)
     t = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
