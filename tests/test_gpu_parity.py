@@ -222,14 +222,15 @@ def test_config3_pcd10_full_size_carried_state(ops, oracle):
     for step in range(3):
         v_bin, _, _, _, y1h = synth_inputs(B, V, H, C, 60 + step)
         off, row0 = (3 * k + 1) * step, 256 * step
-        ops.cd_step(P, G, dev(ops, v_bin.astype(np.uint8)), dev(ops, y1h), k, seed, off, row0, cv, cy, True, lr, 1.0,
-                    float(B), sparse, ws)
+        out = ops.cd_step(P, G, dev(ops, v_bin.astype(np.uint8)), dev(ops, y1h), k, seed, off, row0, cv, cy, True, lr, 1.0,
+                          float(B), sparse, ws)
+        assert out[2] is cv and out[3] is cy                        # PCD: (v_k, y_k) are written straight into the chains
         ph0, vk, yk, phk = oracle.rbm_cd_chain(v_bin, y1h, W, b, d, U, c, k, seed, off, row0, cv_o, cy_o)
         g = oracle.rbm_two_phase_grad(v_bin, y1h, ph0, vk, yk, phk)
         oracle.rbm_update(W, b, d, U, c, *g, lr, 1.0, float(B), sparse)
         assert_bitwise(ws[0], ph0, f"p(h0), step {step}")
-        assert np.array_equal(ws[2].cpu().numpy(), vk.astype(np.uint8)), f"v_k, step {step}"
-        assert_bitwise(ws[3], yk, f"y_k, step {step}")
+        assert np.array_equal(cv.cpu().numpy(), vk.astype(np.uint8)), f"v_k, step {step}"
+        assert_bitwise(cy, yk, f"y_k, step {step}")
         assert_bitwise(ws[4], phk, f"p(h_k), step {step}")
         assert np.array_equal(cv.cpu().numpy(), cv_o.astype(np.uint8)), f"persistent v, step {step}"
         assert_bitwise(cy, cy_o, f"persistent y, step {step}")
