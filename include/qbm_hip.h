@@ -142,7 +142,7 @@ QBM_API int qbm_f32_to_u8(const float* x, uint8_t* y, long n, void* stream);
 /* caller-owned scratch of one CD-k / PCD step; the Gibbs states are uint8 {0,1} */
 typedef struct {
     float* ph0;   /* [B,H] positive-phase hidden probabilities */
-    uint8_t* h;   /* [B,H] current hidden sample */
+    uint8_t* h;   /* [B,H] hidden sample h_0 .. h_{k-1} (h_k is never drawn: the gradient uses p(h_k)) */
     uint8_t* vk;  /* [B,V] */
     float* yk;    /* [B,C] one-hot */
     float* phk;   /* [B,H] */

@@ -1167,7 +1167,9 @@ int qbm_rbm_cd_chain(const qbm_rbm_params* P, const void* v0, int v0_dtype, cons
         // v_t and y_t both depend on h_{t-1} only: one launch (class conditional as aux workgroups)
         if (int rc = launch_visible(P, ws->h, QBM_U8, B, nullptr, nullptr, v_out, nullptr, y_out, seed, o - 2, o - 1, row0, st))
             return rc;
-        if (int rc = launch_hidden(P, v_out, QBM_U8, y_out, B, ws->phk, nullptr, ws->h, 0, seed, o, row0, st)) return rc;
+        // the hidden SAMPLE of the last iteration has no consumer (the gradient uses p(h_k)): no draw, no store
+        if (int rc = launch_hidden(P, v_out, QBM_U8, y_out, B, ws->phk, nullptr, t < k ? ws->h : nullptr, 0, seed, o, row0, st))
+            return rc;
     }
     return QBM_OK;
 }
