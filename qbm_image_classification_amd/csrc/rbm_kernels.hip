@@ -79,6 +79,8 @@ struct HiddenArgs {
     uint64_t seed, offset;
     uint32_t row0;
     bool vecO;
+    bool clsDma;   // the class-term operands (U tile, y rows) of a wavefront come by two LDS-DMA transfers
+    int ldsCls;    // byte offset of the per-wavefront class-term scratch (2 KiB each) in the dynamic LDS
 };
 
 template <class TA, bool FAST, int MODE, int CM>
@@ -109,6 +111,13 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
     // kernel AND out of its head: the loads are issued in `pre0` (unconditional, indices clamped, untracked by the
     // compiler: gload_*), i.e. behind the first operand transfers of the contraction, and consumed in `pre`, while those
     // transfers are in flight.
+    // Class term, FAST path: every vector-memory instruction of a wavefront costs the kernel's start as much as a 1 KiB
+    // operand transfer, so the 3*C loads per thread (y row, two U columns) are replaced by TWO LDS-DMA transfers per
+    // wavefront -- the 16-column tile of U (C x 64 B) and the y rows of its 8 strip rows (8 x 4C B, contiguous) -- into a
+    // 2 KiB scratch of its own, read back with ds_read in `pre`.
+    const bool cls_dma = FAST && with_cls && a.clsDma;
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+    char* cls_lds = lds + a.ldsCls + wv * 2048;
     uint32_t d_raw[2] = {0u, 0u}, y_raw[CM], u_raw[CM][2];
     auto pre0 = [&]() {
         if (pair) {
@@ -119,7 +128,14 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
             gload_b32(d_raw[0], a.d + min(j0, a.H - 1));
             gload_b32(d_raw[1], a.d + min(j0 + 1, a.H - 1));
         }
-        if (with_cls) {
+        if (cls_dma) {
+            // lanes 0..4C-1: 16-byte chunk (class = lane/4, columns n0 + 4*(lane%4) ..) of the U tile;
+            // lanes 0..2C-1: 16-byte chunk `lane` of the 8*C floats of rows m0 + 8*wv ..; everything else, and rows beyond
+            // the batch, read as zeros through the descriptors' range check
+            const rsrc_t ru = make_rsrc(a.U, (unsigned)(a.C * a.H * 4)), ry = make_rsrc(a.y, (unsigned)(a.B * a.C * 4));
+            blds16(ru, lane < 4 * a.C ? (unsigned)(((lane >> 2) * a.H + n0 + 4 * (lane & 3)) * 4) : kOOB, cls_lds);
+            blds16(ry, lane < 2 * a.C ? (unsigned)(((m0 + 8 * wv) * a.C + 4 * lane) * 4) : kOOB, cls_lds + 1024);
+        } else if (with_cls) {
 #pragma unroll
             for (int c = 0; c < CM; ++c) gload_b32(y_raw[c], a.y + (long)i_c * a.C + min(c, a.C - 1));
             if (pair) {
@@ -149,16 +165,31 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
             uu[1] = (j0 & 2) ? u4[3] : u4[1];
             asm volatile("" : "+v"(uu[0]), "+v"(uu[1]));   // ... nor sunk behind the wait below
         }
-        vm_wait(n_younger);   // the loads of pre0 (and everything older) have landed; n_younger transfers stay in flight
+        vm_wait(n_younger);   // the loads / transfers of pre0 (and everything older) have landed; n_younger transfers stay in flight
         asm volatile("" : "+v"(d_raw[0]), "+v"(d_raw[1]));
         dv[0] = __uint_as_float(d_raw[0]); dv[1] = __uint_as_float(d_raw[1]);
+        if (cls_dma) {
+            // this wavefront's own transfers: visible to its ds_reads behind the vm_wait above.  Row r of the wavefront
+            // (= lane/8) has its C floats at 1024 + 4*C*r; column pair (lane%8) of class c sits at 64*c + 8*(lane%8).
+            // Reads beyond class C-1 return whatever the scratch holds: masked below.
+            const uint32_t ya = lds_off(cls_lds) + 1024u + (uint32_t)(4 * a.C * (lane >> 3)), ua = lds_off(cls_lds) + 8u * (lane & 7);
+#pragma unroll
+            for (int c = 0; c < CM; ++c) {
+                u32x2 t;
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(y_raw[c]) : "v"(ya), "n"(4 * c) : "memory");
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(t) : "v"(ua), "n"(64 * c) : "memory");
+                u_raw[c][0] = t[0]; u_raw[c][1] = t[1];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         if (with_cls) {
 #pragma unroll
             for (int c = 0; c < CM; ++c) {
                 asm volatile("" : "+v"(y_raw[c]), "+v"(u_raw[c][0]), "+v"(u_raw[c][1]));
-                const float yv = (c < a.C) ? __uint_as_float(y_raw[c]) : 0.f;
-                cls[0] = __builtin_fmaf(yv, __uint_as_float(u_raw[c][0]), cls[0]);
-                cls[1] = __builtin_fmaf(yv, __uint_as_float(u_raw[c][1]), cls[1]);
+                const bool on = c < a.C;
+                const float yv = on ? __uint_as_float(y_raw[c]) : 0.f;
+                cls[0] = __builtin_fmaf(yv, on ? __uint_as_float(u_raw[c][0]) : 0.f, cls[0]);
+                cls[1] = __builtin_fmaf(yv, on ? __uint_as_float(u_raw[c][1]) : 0.f, cls[1]);
             }
         }
     };
@@ -877,12 +908,21 @@ int launch_hidden_t(const qbm_rbm_params* P, const void* v, const float* y, int 
     HiddenArgs a{v, y, P->W, P->d, P->U, p, s, s8, B, P->V, P->H, P->C, panel_for<MT, NT, ASZ>(P->V), seed, offset, row0,
                  // column pairs: 8-byte accesses to p / h_f32 / d / U, 2-byte accesses to h_u8
                  (P->H % 2 == 0) && (!p || aligned8(p)) && (!s || aligned8(s)) && (!s8 || aligned2(s8)) &&
-                     aligned8(P->d) && aligned8(P->U)};
+                     aligned8(P->d) && aligned8(P->U),
+                 false, 0};
     // LDS-DMA path: whole 16-k pieces, 16-byte aligned units, descriptors below 2 GiB
     const bool fast = (P->V % 16 == 0) && aligned16(v) && (P->H % 4 == 0) && aligned16(P->W) &&
                       small2g((long)B * P->V, ASZ) && small2g((long)P->V * P->H, 4);
     const int nM = (B + 16 * MT - 1) / (16 * MT), nN = (P->H + 16 * NT - 1) / (16 * NT);
-    const size_t lds = strip_lds_bytes<MT, NT, ASZ>(a.KP);
+    size_t lds = strip_lds_bytes<MT, NT, ASZ>(a.KP);
+    // class term by LDS-DMA: one transfer instruction must hold the U tile (4*C chunks of 16 B) and the 8 y rows of a
+    // wavefront (2*C chunks); whole, 16-byte aligned chunks only
+    a.clsDma = fast && mode == 0 && y && NT == 1 && MT == 2 && 4 * P->C <= 64 && ((long)B * P->C) % 4 == 0 && aligned16(y) &&
+               aligned16(P->U) && small2g((long)B * P->C, 4) && small2g((long)P->C * P->H, 4);
+    if (a.clsDma) {
+        a.ldsCls = (int)lds;
+        lds += 4 * 2048;
+    }
 #define QBM_LAUNCH(F, MODE, CM)                                                                  \
     {                                                                                            \
         if (int rc = set_lds(k_hidden<TA, F, MODE, CM>, lds)) return rc;                         \
