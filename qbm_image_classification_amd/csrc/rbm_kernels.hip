@@ -118,43 +118,51 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
     const bool cls_dma = FAST && with_cls && a.clsDma;
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
     char* cls_lds = lds + a.ldsCls + wv * 2048;
-    uint32_t d_raw[2] = {0u, 0u}, y_raw[CM], u_raw[CM][2];
+    // Three ways to the operands of the bias / class term, one per case, each with variables of its own: a register
+    // written by an untracked load (gload_*) must reach its consumer without passing through a copy or a merge with another
+    // definition -- the copy would run before the data has arrived.
+    //   pair, class term by LDS-DMA : d by gload_b64, U tile and y rows by two transfers, read back with ds_read in `pre`
+    //   pair                        : d, y, U by gload_* (untracked), consumed behind vm_wait in `pre`
+    //   not pair (ragged / unaligned columns): ordinary loads, the compiler places the waits
+    u32x2 d_a = {0u, 0u}, u_a[CM];
+    uint32_t y_a[CM];
+    float d_g[2] = {0.f, 0.f}, y_g[CM], u_g[CM][2];
     auto pre0 = [&]() {
         if (pair) {
-            u32x2 t;
-            gload_b64(t, a.d + j0);
-            d_raw[0] = t[0]; d_raw[1] = t[1];
+            gload_b64(d_a, a.d + j0);
+            if (cls_dma) {
+                // lanes 0..4C-1: 16-byte chunk (class = lane/4, columns n0 + 4*(lane%4) ..) of the U tile;
+                // lanes 0..2C-1: 16-byte chunk `lane` of the 8*C floats of rows m0 + 8*wv ..; everything else, and rows
+                // beyond the batch, read as zeros through the descriptors' range check
+                const rsrc_t ru = make_rsrc(a.U, (unsigned)(a.C * a.H * 4)), ry = make_rsrc(a.y, (unsigned)(a.B * a.C * 4));
+                blds16(ru, lane < 4 * a.C ? (unsigned)(((lane >> 2) * a.H + n0 + 4 * (lane & 3)) * 4) : kOOB, cls_lds);
+                blds16(ry, lane < 2 * a.C ? (unsigned)(((m0 + 8 * wv) * a.C + 4 * lane) * 4) : kOOB, cls_lds + 1024);
+            } else if (with_cls) {
+#pragma unroll
+                for (int c = 0; c < CM; ++c) gload_b32(y_a[c], a.y + (long)i_c * a.C + min(c, a.C - 1));
+#pragma unroll
+                for (int c = 0; c < CM; ++c) gload_b64(u_a[c], a.U + (long)min(c, a.C - 1) * a.H + j0);
+            }
         } else {
-            gload_b32(d_raw[0], a.d + min(j0, a.H - 1));
-            gload_b32(d_raw[1], a.d + min(j0 + 1, a.H - 1));
-        }
-        if (cls_dma) {
-            // lanes 0..4C-1: 16-byte chunk (class = lane/4, columns n0 + 4*(lane%4) ..) of the U tile;
-            // lanes 0..2C-1: 16-byte chunk `lane` of the 8*C floats of rows m0 + 8*wv ..; everything else, and rows beyond
-            // the batch, read as zeros through the descriptors' range check
-            const rsrc_t ru = make_rsrc(a.U, (unsigned)(a.C * a.H * 4)), ry = make_rsrc(a.y, (unsigned)(a.B * a.C * 4));
-            blds16(ru, lane < 4 * a.C ? (unsigned)(((lane >> 2) * a.H + n0 + 4 * (lane & 3)) * 4) : kOOB, cls_lds);
-            blds16(ry, lane < 2 * a.C ? (unsigned)(((m0 + 8 * wv) * a.C + 4 * lane) * 4) : kOOB, cls_lds + 1024);
-        } else if (with_cls) {
-#pragma unroll
-            for (int c = 0; c < CM; ++c) gload_b32(y_raw[c], a.y + (long)i_c * a.C + min(c, a.C - 1));
-            if (pair) {
+            d_g[0] = a.d[min(j0, a.H - 1)];
+            d_g[1] = a.d[min(j0 + 1, a.H - 1)];
+            if (with_cls) {
 #pragma unroll
                 for (int c = 0; c < CM; ++c) {
-                    u32x2 t;
-                    gload_b64(t, a.U + (long)min(c, a.C - 1) * a.H + j0);
-                    u_raw[c][0] = t[0]; u_raw[c][1] = t[1];
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < CM; ++c) {
-                    gload_b32(u_raw[c][0], a.U + (long)min(c, a.C - 1) * a.H + min(j0, a.H - 1));
-                    gload_b32(u_raw[c][1], a.U + (long)min(c, a.C - 1) * a.H + min(j0 + 1, a.H - 1));
+                    y_g[c] = a.y[(long)i_c * a.C + min(c, a.C - 1)];
+                    u_g[c][0] = a.U[(long)min(c, a.C - 1) * a.H + min(j0, a.H - 1)];
+                    u_g[c][1] = a.U[(long)min(c, a.C - 1) * a.H + min(j0 + 1, a.H - 1)];
                 }
             }
         }
     };
     float dv[2], cls[2] = {0.f, 0.f}, uu[2] = {0.f, 0.f};
+    auto chain = [&](int c, float y, float u0, float u1) {   // class c of the class term (classes >= C enter as 0 * 0)
+        const bool on = c < a.C;
+        const float yv = on ? y : 0.f;
+        cls[0] = __builtin_fmaf(yv, on ? u0 : 0.f, cls[0]);
+        cls[1] = __builtin_fmaf(yv, on ? u1 : 0.f, cls[1]);
+    };
     auto pre = [&](int n_younger) {
         if (MODE == 0 && (a.s || a.s8)) {
             // one Philox block serves columns 4*(j0>>2) .. +3; this thread's pair is its lower or upper half
@@ -165,31 +173,40 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
             uu[1] = (j0 & 2) ? u4[3] : u4[1];
             asm volatile("" : "+v"(uu[0]), "+v"(uu[1]));   // ... nor sunk behind the wait below
         }
+        if (!pair) {
+            dv[0] = d_g[0]; dv[1] = d_g[1];
+            if (with_cls) {
+#pragma unroll
+                for (int c = 0; c < CM; ++c) chain(c, y_g[c], u_g[c][0], u_g[c][1]);
+            }
+            return;
+        }
         vm_wait(n_younger);   // the loads / transfers of pre0 (and everything older) have landed; n_younger transfers stay in flight
-        asm volatile("" : "+v"(d_raw[0]), "+v"(d_raw[1]));
-        dv[0] = __uint_as_float(d_raw[0]); dv[1] = __uint_as_float(d_raw[1]);
+        asm volatile("" : "+v"(d_a));
+        dv[0] = __uint_as_float(d_a[0]); dv[1] = __uint_as_float(d_a[1]);
         if (cls_dma) {
             // this wavefront's own transfers: visible to its ds_reads behind the vm_wait above.  Row r of the wavefront
             // (= lane/8) has its C floats at 1024 + 4*C*r; column pair (lane%8) of class c sits at 64*c + 8*(lane%8).
-            // Reads beyond class C-1 return whatever the scratch holds: masked below.
+            // Reads beyond class C-1 return whatever the scratch holds: masked in `chain`.
             const uint32_t ya = lds_off(cls_lds) + 1024u + (uint32_t)(4 * a.C * (lane >> 3)), ua = lds_off(cls_lds) + 8u * (lane & 7);
+            uint32_t y_l[CM];
+            u32x2 u_l[CM];
 #pragma unroll
             for (int c = 0; c < CM; ++c) {
-                u32x2 t;
-                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(y_raw[c]) : "v"(ya), "n"(4 * c) : "memory");
-                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(t) : "v"(ua), "n"(64 * c) : "memory");
-                u_raw[c][0] = t[0]; u_raw[c][1] = t[1];
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(y_l[c]) : "v"(ya), "n"(4 * c) : "memory");
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(u_l[c]) : "v"(ua), "n"(64 * c) : "memory");
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        if (with_cls) {
 #pragma unroll
             for (int c = 0; c < CM; ++c) {
-                asm volatile("" : "+v"(y_raw[c]), "+v"(u_raw[c][0]), "+v"(u_raw[c][1]));
-                const bool on = c < a.C;
-                const float yv = on ? __uint_as_float(y_raw[c]) : 0.f;
-                cls[0] = __builtin_fmaf(yv, on ? __uint_as_float(u_raw[c][0]) : 0.f, cls[0]);
-                cls[1] = __builtin_fmaf(yv, on ? __uint_as_float(u_raw[c][1]) : 0.f, cls[1]);
+                asm volatile("" : "+v"(y_l[c]), "+v"(u_l[c]));
+                chain(c, __uint_as_float(y_l[c]), __uint_as_float(u_l[c][0]), __uint_as_float(u_l[c][1]));
+            }
+        } else if (with_cls) {
+#pragma unroll
+            for (int c = 0; c < CM; ++c) {
+                asm volatile("" : "+v"(y_a[c]), "+v"(u_a[c]));
+                chain(c, __uint_as_float(y_a[c]), __uint_as_float(u_a[c][0]), __uint_as_float(u_a[c][1]));
             }
         }
     };
