@@ -128,16 +128,17 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
     uint32_t y_a[CM];
     float d_g[2] = {0.f, 0.f}, y_g[CM], u_g[CM][2];
     auto pre0 = [&]() {
+        if (cls_dma) {   // by ALL lanes of the wavefront (a lane masked off would leave its chunk out)
+            // lanes 0..4C-1: 16-byte chunk (class = lane/4, columns n0 + 4*(lane%4) ..) of the U tile;
+            // lanes 0..2C-1: 16-byte chunk `lane` of the 8*C floats of rows m0 + 8*wv ..; everything else, and rows
+            // beyond the batch, read as zeros through the descriptors' range check
+            const rsrc_t ru = make_rsrc(a.U, (unsigned)(a.C * a.H * 4)), ry = make_rsrc(a.y, (unsigned)(a.B * a.C * 4));
+            blds16(ru, lane < 4 * a.C ? (unsigned)(((lane >> 2) * a.H + n0 + 4 * (lane & 3)) * 4) : kOOB, cls_lds);
+            blds16(ry, lane < 2 * a.C ? (unsigned)(((m0 + 8 * wv) * a.C + 4 * lane) * 4) : kOOB, cls_lds + 1024);
+        }
         if (pair) {
             gload_b64(d_a, a.d + j0);
-            if (cls_dma) {
-                // lanes 0..4C-1: 16-byte chunk (class = lane/4, columns n0 + 4*(lane%4) ..) of the U tile;
-                // lanes 0..2C-1: 16-byte chunk `lane` of the 8*C floats of rows m0 + 8*wv ..; everything else, and rows
-                // beyond the batch, read as zeros through the descriptors' range check
-                const rsrc_t ru = make_rsrc(a.U, (unsigned)(a.C * a.H * 4)), ry = make_rsrc(a.y, (unsigned)(a.B * a.C * 4));
-                blds16(ru, lane < 4 * a.C ? (unsigned)(((lane >> 2) * a.H + n0 + 4 * (lane & 3)) * 4) : kOOB, cls_lds);
-                blds16(ry, lane < 2 * a.C ? (unsigned)(((m0 + 8 * wv) * a.C + 4 * lane) * 4) : kOOB, cls_lds + 1024);
-            } else if (with_cls) {
+            if (!cls_dma && with_cls) {
 #pragma unroll
                 for (int c = 0; c < CM; ++c) gload_b32(y_a[c], a.y + (long)i_c * a.C + min(c, a.C - 1));
 #pragma unroll
