@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QBM_ABI_VERSION 7
+#define QBM_ABI_VERSION 8
 #define QBM_MAX_CLASSES 15 /* class rows + the bias row share one 16-row gradient tile */
 #define QBM_MAX_QUBO_VARS 1024
 
@@ -241,6 +241,46 @@ QBM_API int qbm_qubo_gibbs(const float* lin, const float* J, int B, int R, int n
 QBM_API int qbm_qubo_gibbs_ex(const float* lin, const float* J, int B, int R, int n, int sweeps, float beta0,
                               float beta1, uint64_t seed, uint64_t offset, uint32_t chain0, uint8_t* states,
                               double* mean, void* stream);
+
+/* The same with the annealing range of every image read from DEVICE memory: beta_dev[B,2] = (hot, cold) per image, as
+ * written by qbm_qbm_beta_range (no host round trip between building the QUBO and sampling it); beta_dev == NULL: the
+ * scalars beta0 / beta1 for every image. */
+QBM_API int qbm_qubo_gibbs_dev(const float* lin, const float* J, int B, int R, int n, int sweeps, const float* beta_dev,
+                               float beta0, float beta1, uint64_t seed, uint64_t offset, uint32_t chain0,
+                               uint8_t* states, double* mean, void* stream);
+
+/* ---- Disc_QBM with device-resident parameters ---------------------------------------------------
+ * theta = [W_vh (1+D)*H | W_vo D | b_h H | b_o 1] float64, the reference's arrays (src/model/faster_dqbm.py:196-216:
+ * weights_all_visible_to_hidden with row 0 = label row, weights_clamped_visible_to_output, biases_hidden,
+ * biases_output) in one device buffer; statistics and their differences use the same layout. */
+
+/* x-dependent QUBO diagonal (qbm_qbm_linear_fields below) with the parameters read from theta. */
+QBM_API int qbm_qbm_linear_fields_dev(const double* X, const int32_t* labels, const double* theta, int B, int D, int H,
+                                      double beta_eff, float* lin, void* stream);
+
+/* Image-independent couplings of Disc_QBM.create_qubo_matrix_from (src/model/faster_dqbm.py:242-243 clamped: W_hh;
+ * :256-271 unclamped: label row of W_vh between the output node and the hidden nodes, W_hh) as the symmetric fp32
+ * J[n,n] (zero diagonal) the sampler takes: J_ab = fp32(Q_ab / beta_eff).  w_label = W_vh row 0 ([H], unclamped only),
+ * W_hh [H,H] float64 upper triangle or NULL (restricted model).  Also rowabs[n] = sum_b |J_ab| and rowmin[n] = smallest
+ * non-zero |J_ab| of the row (0 if none), float64: inputs of qbm_qbm_beta_range. */
+QBM_API int qbm_qbm_couplings(const double* w_label, const double* W_hh, int H, int clamped, double beta_eff, float* J,
+                              double* rowabs, double* rowmin, void* stream);
+
+/* Annealing range per image, beta[B,2] fp32 = (hot, cold): hot = ln 2 / max_i (|lin_i| + rowabs_i),
+ * cold = ln 100 / (smallest non-zero |coefficient| of lin_b and J), cold clamped to [10 hot, 1e4 hot]; (0.1, 1) for a QUBO
+ * without usable coefficients.  Replaces the automatic beta_range of the reference's annealer (dwave-neal, absent here). */
+QBM_API int qbm_qbm_beta_range(const float* lin, const double* rowabs, const double* rowmin, int B, int n, float* beta,
+                               void* stream);
+
+/* Statistics of both phases and their difference in one pass (Disc_QBM.get_average_configuration_batch :754-848 twice,
+ * then `clamped - unclamped` of train_for_one_iteration :1023-1040): mean_c[B,H], mean_u[B,1+H] float64 per-image means
+ * over reads -> diff[theta layout].  Sequential over the images, like qbm_qbm_batch_stats. */
+QBM_API int qbm_qbm_stats_diff(const double* X, const int32_t* labels, const double* mean_c, const double* mean_u, int B,
+                               int D, int H, double* diff, void* stream);
+
+/* theta -= lr * (diff / batch), src/model/faster_dqbm.py:1041-1059 (batch = the GLOBAL minibatch size when diff was
+ * all-reduced over data-parallel ranks). */
+QBM_API int qbm_qbm_apply_update(double* theta, const double* diff, int D, int H, double lr, double batch, void* stream);
 
 /* Disc_QBM.get_average_configuration_batch, src/model/faster_dqbm.py:754-848, from the per-image means over
  * reads (float64, images accumulated in order).  labels != NULL = clamped phase (mean[B,H]), NULL = unclamped

@@ -323,6 +323,42 @@ def qbm_couplings(W_vh, W_hh, clamped: bool, beta_eff=1.0):
     return J
 
 
+def qbm_coupling_stats(J):
+    """rowabs[n] = sum_b |J_ab| (float64, ascending b: cumsum is sequential), rowmin[n] = smallest non-zero |J_ab| or 0:
+    the second and third output of qbm_qbm_couplings (include/qbm_hip.h)."""
+    A = np.abs(np.asarray(J, dtype=np.float32)).astype(np.float64)
+    rowabs = np.cumsum(A, axis=1)[:, -1] if A.shape[1] else np.zeros(A.shape[0])
+    masked = np.where(A > 0, A, np.inf)
+    rowmin = masked.min(axis=1)
+    return rowabs, np.where(np.isfinite(rowmin), rowmin, 0.0)
+
+
+def qbm_beta_range(lin, rowabs, rowmin):
+    """Per-image annealing range (hot, cold) as qbm_qbm_beta_range states it -> float32 [B,2].  max / min are exact in any
+    order; the two divisions and the clamp are single float64 operations."""
+    lin = np.abs(np.asarray(lin, dtype=np.float32)).astype(np.float64)
+    B = lin.shape[0]
+    out = np.empty((B, 2), np.float32)
+    for b in range(B):
+        big = float(np.max(lin[b] + rowabs)) if lin.shape[1] else 0.0
+        cands = np.concatenate([lin[b][lin[b] > 0], np.asarray(rowmin)[np.asarray(rowmin) > 0]])
+        hot, cold = 0.1, 1.0
+        if cands.size and big > 0 and np.isfinite(big):
+            mn = float(cands.min())
+            hot = 0.6931471805599453 / big
+            cold = 4.605170185988092 / mn
+            cold = min(max(cold, 10.0 * hot), 1e4 * hot)
+        out[b] = (np.float32(hot), np.float32(cold))
+    return out
+
+
+def qbm_stats_diff(X, labels, mean_c, mean_u, H):
+    """statistics(clamped) - statistics(unclamped) in the theta layout [W_vh | W_vo | b_h | b_o] (qbm_qbm_stats_diff)."""
+    c = qbm_batch_stats(X, labels, mean_c, H)
+    u = qbm_batch_stats(X, None, mean_u, H)
+    return np.concatenate([a.reshape(-1) for a in c]) - np.concatenate([a.reshape(-1) for a in u])
+
+
 def qubo_gibbs(lin, J, reads, sweeps, beta0=1.0, beta1=1.0, seed=0, offset=0, chain0=0):
     """-> (states u8 [B,R,n], mean f64 [B,n]); chain0 = global index of the first chain (sharded minibatches)"""
     lin, J = _f32(lin), _f32(J)

@@ -8,7 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libqbm_hip.so")
 
-QBM_ABI_VERSION = 7
+QBM_ABI_VERSION = 8
 QBM_MAX_CLASSES = 15
 QBM_F32, QBM_U8 = 0, 1
 
@@ -71,6 +71,12 @@ SIGNATURES = {
     "qbm_test_uniform": [_u64, _u64, _u32, _i, _i, _p, _p],
     "qbm_qubo_gibbs": [_p, _p, _i, _i, _i, _i, _f, _f, _u64, _u64, _p, _p, _p],
     "qbm_qubo_gibbs_ex": [_p, _p, _i, _i, _i, _i, _f, _f, _u64, _u64, _u32, _p, _p, _p],
+    "qbm_qubo_gibbs_dev": [_p, _p, _i, _i, _i, _i, _p, _f, _f, _u64, _u64, _u32, _p, _p, _p],
+    "qbm_qbm_linear_fields_dev": [_p, _p, _p, _i, _i, _i, C.c_double, _p, _p],
+    "qbm_qbm_couplings": [_p, _p, _i, _i, C.c_double, _p, _p, _p, _p],
+    "qbm_qbm_beta_range": [_p, _p, _p, _i, _i, _p, _p],
+    "qbm_qbm_stats_diff": [_p, _p, _p, _p, _i, _i, _i, _p, _p],
+    "qbm_qbm_apply_update": [_p, _p, _i, _i, C.c_double, C.c_double, _p],
     "qbm_qbm_batch_stats": [_p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p],
     "qbm_qbm_linear_fields": [_p, _p, _p, _p, _p, C.c_double, _i, _i, _i, C.c_double, _p, _p],
 }

@@ -98,10 +98,14 @@ __device__ __forceinline__ void row_of_tile(const JR& jr, int t, int p, int lane
 // One chain (image b, read r) on one wavefront.
 template <int NF, class JR>
 __device__ __forceinline__ void gibbs_chain(const float* __restrict__ lin, const JR& jr, int ch, int R, int n, int sweeps,
-                                            float beta0, float beta1, uint64_t seed, uint64_t offset, uint32_t chain0,
-                                            uint8_t* __restrict__ states, int lane)
+                                            float beta0, float beta1, const float* __restrict__ beta_dev, uint64_t seed,
+                                            uint64_t offset, uint32_t chain0, uint8_t* __restrict__ states, int lane)
 {
     const int b = ch / R;
+    if (beta_dev) {   // per-image annealing range [B,2] written by k_qbm_beta (no host round trip)
+        beta0 = beta_dev[2 * b];
+        beta1 = beta_dev[2 * b + 1];
+    }
     const uint32_t row = chain0 + (uint32_t)ch;   // Philox row: the GLOBAL chain index (sharding-invariant draws)
     float F[NF], thr[NF], jrow[NF];
     bool st[NF];   // this lane's spin of tile t
@@ -184,15 +188,15 @@ __device__ __forceinline__ void gibbs_chain(const float* __restrict__ lin, const
 template <int NF>
 __global__ __launch_bounds__(256) void k_qubo_gibbs(const float* __restrict__ lin, const float* __restrict__ J,
                                                     int nchains, int R, int n, int sweeps, float beta0,
-                                                    float beta1, uint64_t seed, uint64_t offset, uint32_t chain0,
-                                                    uint8_t* __restrict__ states)
+                                                    float beta1, const float* __restrict__ beta_dev, uint64_t seed,
+                                                    uint64_t offset, uint32_t chain0, uint8_t* __restrict__ states)
 {
     const int lane = threadIdx.x & 63;
     const int ch = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (ch >= nchains) return;
     JGlobal jr{J, n};
     jr.setup(lane);
-    gibbs_chain<NF>(lin, jr, ch, R, n, sweeps, beta0, beta1, seed, offset, chain0, states, lane);
+    gibbs_chain<NF>(lin, jr, ch, R, n, sweeps, beta0, beta1, beta_dev, seed, offset, chain0, states, lane);
 }
 
 // J triangle in LDS: one workgroup of 16 wavefronts per CU, every wavefront walks chains ch = wave id, + total waves, ...
@@ -201,7 +205,8 @@ template <int NF>
 __global__ __launch_bounds__(64 * kGibbsLdsWaves) void k_qubo_gibbs_lds(const float* __restrict__ lin,
                                                                         const float* __restrict__ J, int nchains, int R,
                                                                         int n, int sweeps, float beta0, float beta1,
-                                                                        uint64_t seed, uint64_t offset, uint32_t chain0,
+                                                                        const float* __restrict__ beta_dev, uint64_t seed,
+                                                                        uint64_t offset, uint32_t chain0,
                                                                         uint8_t* __restrict__ states)
 {
     extern __shared__ float tri[];
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(64 * kGibbsLdsWaves) void k_qubo_gibbs_lds(const fl
     const int waves = (int)blockDim.x >> 6;
     const int total = gridDim.x * waves;
     for (int ch = blockIdx.x * waves + w; ch < nchains; ch += total)
-        gibbs_chain<NF>(lin, jr, ch, R, n, sweeps, beta0, beta1, seed, offset, chain0, states, lane);
+        gibbs_chain<NF>(lin, jr, ch, R, n, sweeps, beta0, beta1, beta_dev, seed, offset, chain0, states, lane);
 }
 
 // mean over reads, float64: exact count / R  (np.average(np_samples, axis=0) on {0,1} samples,
@@ -275,9 +280,11 @@ __global__ __launch_bounds__(256) void k_batch_stats(const double* __restrict__ 
 // sequential over k, one thread per (image, variable); rounded to fp32 for the sampler.
 __global__ __launch_bounds__(256) void k_linear_fields(const double* __restrict__ X, const int* __restrict__ labels,
                                                        const double* __restrict__ W_vh, const double* __restrict__ W_vo,
-                                                       const double* __restrict__ b_h, double b_o, int B, int D, int H,
+                                                       const double* __restrict__ b_h, double b_o_val,
+                                                       const double* __restrict__ b_o_dev, int B, int D, int H,
                                                        double beta_eff, float* __restrict__ lin)
 {
+    const double b_o = b_o_dev ? b_o_dev[0] : b_o_val;   // device-resident parameters: the output bias by address
     const int n = labels ? H : H + 1;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * n) return;
@@ -295,9 +302,133 @@ __global__ __launch_bounds__(256) void k_linear_fields(const double* __restrict_
     lin[idx] = (float)((b_h[j] + a) / beta_eff);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Device-resident Disc_QBM training state.  theta = [W_vh (1+D)*H | W_vo D | b_h H | b_o 1],
+// float64 like the reference's numpy arrays (src/model/faster_dqbm.py:196-216); statistics use the same layout.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline long qbm_theta_len(int D, int H) { return (long)(1 + D) * H + D + H + 1; }
+
+// Image-independent couplings of the QUBO (create_qubo_matrix_from, :242-243 clamped, :256-271 unclamped) as the sampler
+// wants them: symmetric fp32 J with zero diagonal, J_ab = fp32(Q_ab / beta_eff) of the upper-triangular Q.  One thread per
+// row; also the row's sum of |J| (float64, ascending columns) and its smallest non-zero |J| (0 if none): the
+// coefficient statistics of the annealing range (k_qbm_beta).
+__global__ __launch_bounds__(256) void k_qbm_couplings(const double* __restrict__ w_label /* W_vh row 0: [H], unclamped only */,
+                                                       const double* __restrict__ W_hh /* [H,H] upper triangle, or null */,
+                                                       int H, int clamped, double beta_eff, float* __restrict__ J,
+                                                       double* __restrict__ rowabs, double* __restrict__ rowmin)
+{
+    const int n = clamped ? H : H + 1, o = clamped ? 0 : 1;
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    double sum = 0.0, mn = 0.0;
+    for (int b = 0; b < n; ++b) {
+        float v = 0.f;
+        if (a != b) {
+            if (!clamped && (a == 0 || b == 0)) v = (float)(w_label[(a == 0 ? b : a) - 1] / beta_eff);
+            else if (W_hh) {
+                const int i = min(a, b) - o, j = max(a, b) - o;
+                v = (float)(W_hh[(long)i * H + j] / beta_eff);
+            }
+        }
+        J[(long)a * n + b] = v;
+        const double av = fabs((double)v);
+        sum += av;
+        if (av > 0.0 && (mn == 0.0 || av < mn)) mn = av;
+    }
+    rowabs[a] = sum;
+    rowmin[a] = mn;
+}
+
+// Annealing range of every image's QUBO (what simulated annealers derive from the coefficients; sampler.auto_beta_range is
+// the host statement of the same rule):  hot = ln 2 / max_i (|lin_i| + sum_j |J_ij|)  (half of the largest single flip is
+// accepted),  cold = ln 100 / (smallest non-zero |coefficient|),  cold clamped to [10 hot, 1e4 hot];  (0.1, 1) if the
+// QUBO has no usable coefficient.  float64 (max / min are exact: any reduction order gives the same bits), rounded to
+// fp32 for the sampler.  One wavefront per image.
+__global__ __launch_bounds__(64) void k_qbm_beta(const float* __restrict__ lin, const double* __restrict__ rowabs,
+                                                 const double* __restrict__ rowmin, int B, int n, float* __restrict__ beta)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    double big = 0.0, mn = 0.0;
+    for (int i = lane; i < n; i += 64) {
+        const double al = fabs((double)lin[(long)b * n + i]);
+        big = fmax(big, al + rowabs[i]);
+        if (al > 0.0 && (mn == 0.0 || al < mn)) mn = al;
+        const double rm = rowmin[i];
+        if (rm > 0.0 && (mn == 0.0 || rm < mn)) mn = rm;
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double ob = __shfl_xor(big, off, 64), om = __shfl_xor(mn, off, 64);
+        big = fmax(big, ob);
+        if (om > 0.0 && (mn == 0.0 || om < mn)) mn = om;
+    }
+    if (lane != 0) return;
+    double hot = 0.1, cold = 1.0;
+    if (mn > 0.0 && big > 0.0 && big < __builtin_inf()) {
+        hot = 0.6931471805599453 / big;
+        cold = 4.605170185988092 / mn;
+        cold = fmin(fmax(cold, 10.0 * hot), 1e4 * hot);
+    }
+    beta[2 * b] = (float)hot;
+    beta[2 * b + 1] = (float)cold;
+}
+
+// Both phases' statistics (get_average_configuration_batch, :754-848) and their difference in one pass:
+// diff = stat(clamped means) - stat(unclamped means), each accumulated sequentially over the images like k_batch_stats
+// (same element order: W_vh | W_vo | b_h | b_o).
+__global__ __launch_bounds__(256) void k_qbm_stats_diff(const double* __restrict__ X, const int* __restrict__ labels,
+                                                        const double* __restrict__ mean_c /* [B,H] */,
+                                                        const double* __restrict__ mean_u /* [B,1+H] */, int B, int D,
+                                                        int H, double* __restrict__ diff)
+{
+    const long nW = (long)(1 + D) * H;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nW + D + H + 1) return;
+    const int nu = H + 1;
+    double c = 0.0, u = 0.0;
+    if (idx < nW) {
+        const int k = (int)(idx / H), j = (int)(idx % H);
+        if (k < D) {
+            for (int i = 0; i < B; ++i) {
+                const double x = X[(long)i * D + k];
+                c += x * mean_c[(long)i * H + j];
+                u += x * mean_u[(long)i * nu + 1 + j];
+            }
+        } else {
+            for (int i = 0; i < B; ++i) c += (double)labels[i] * mean_c[(long)i * H + j];   // label row: clamped phase only
+        }
+    } else if (idx < nW + D) {
+        const int k = (int)(idx - nW);
+        for (int i = 0; i < B; ++i) {
+            const double x = X[(long)i * D + k];
+            c += x * (double)labels[i];
+            u += x * mean_u[(long)i * nu];
+        }
+    } else if (idx < nW + D + H) {
+        const int j = (int)(idx - nW - D);
+        for (int i = 0; i < B; ++i) {
+            c += mean_c[(long)i * H + j];
+            u += mean_u[(long)i * nu + 1 + j];
+        }
+    } else {
+        for (int i = 0; i < B; ++i) {
+            c += (double)labels[i];
+            u += mean_u[(long)i * nu];
+        }
+    }
+    diff[idx] = c - u;
+}
+
+// train_for_one_iteration's update (:1023-1059): theta -= lr * (diff / B), element by element, in this order of operations
+__global__ __launch_bounds__(256) void k_qbm_apply(double* __restrict__ theta, const double* __restrict__ diff, long n,
+                                                   double lr, double batch)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) theta[i] = theta[i] - lr * (diff[i] / batch);
+}
+
 template <int NF>
 int launch_gibbs(const float* lin, const float* J, int B, int R, int n, int sweeps, float beta0, float beta1,
-                 uint64_t seed, uint64_t offset, uint32_t chain0, uint8_t* states, hipStream_t st)
+                 const float* beta_dev, uint64_t seed, uint64_t offset, uint32_t chain0, uint8_t* states, hipStream_t st)
 {
     const int nch = B * R;
     const size_t tri_bytes = (size_t)n * (n + 1) / 2 * sizeof(float);
@@ -314,12 +445,12 @@ int launch_gibbs(const float* lin, const float* J, int B, int R, int n, int swee
         int waves = (nch + rounds * wgs - 1) / (rounds * wgs);
         waves = waves < 1 ? 1 : waves > kGibbsLdsWaves ? kGibbsLdsWaves : waves;
         hipLaunchKernelGGL((k_qubo_gibbs_lds<NF>), dim3(wgs), dim3(64 * waves), tri_bytes, st, lin, J, nch, R, n, sweeps,
-                           beta0, beta1, seed, offset, chain0, states);
+                           beta0, beta1, beta_dev, seed, offset, chain0, states);
         QBM_CHECK_LAUNCH("k_qubo_gibbs_lds");
         return QBM_OK;
     }
     hipLaunchKernelGGL((k_qubo_gibbs<NF>), dim3((nch + 3) / 4), dim3(256), 0, st, lin, J, nch, R, n, sweeps, beta0,
-                       beta1, seed, offset, chain0, states);
+                       beta1, beta_dev, seed, offset, chain0, states);
     QBM_CHECK_LAUNCH("k_qubo_gibbs");
     return QBM_OK;
 }
@@ -337,24 +468,32 @@ int qbm_qubo_gibbs(const float* lin, const float* J, int B, int R, int n, int sw
 int qbm_qubo_gibbs_ex(const float* lin, const float* J, int B, int R, int n, int sweeps, float beta0, float beta1,
                       uint64_t seed, uint64_t offset, uint32_t chain0, uint8_t* states, double* mean, void* stream)
 {
+    if (!(beta0 > 0.f) || !(beta1 > 0.f)) return fail(QBM_ERR_ARG, "qubo_gibbs: beta must be positive");
+    return qbm_qubo_gibbs_dev(lin, J, B, R, n, sweeps, nullptr, beta0, beta1, seed, offset, chain0, states, mean, stream);
+}
+
+int qbm_qubo_gibbs_dev(const float* lin, const float* J, int B, int R, int n, int sweeps, const float* beta_dev,
+                       float beta0, float beta1, uint64_t seed, uint64_t offset, uint32_t chain0, uint8_t* states,
+                       double* mean, void* stream)
+{
     if (B < 0 || R < 0) return fail(QBM_ERR_ARG, "qubo_gibbs: negative batch/reads");
     if (B == 0 || R == 0) return QBM_OK;
     if (n <= 0 || n > QBM_MAX_QUBO_VARS) return fail(QBM_ERR_ARG, "qubo_gibbs: n out of range (1..QBM_MAX_QUBO_VARS)");
     if (sweeps < 0) return fail(QBM_ERR_ARG, "qubo_gibbs: sweeps < 0");
-    if (!(beta0 > 0.f) || !(beta1 > 0.f)) return fail(QBM_ERR_ARG, "qubo_gibbs: beta must be positive");
+    if (!beta_dev && (!(beta0 > 0.f) || !(beta1 > 0.f))) return fail(QBM_ERR_ARG, "qubo_gibbs: beta must be positive");
     if (!lin || !J || !states) return fail(QBM_ERR_ARG, "qubo_gibbs: null buffer");
     hipStream_t st = (hipStream_t)stream;
     const int NF = (n + 63) / 64;
     int rc;
     switch (NF) {
-    case 1: rc = launch_gibbs<1>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, chain0, states, st); break;
-    case 2: rc = launch_gibbs<2>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, chain0, states, st); break;
-    case 3: rc = launch_gibbs<3>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, chain0, states, st); break;
-    case 4: rc = launch_gibbs<4>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, chain0, states, st); break;
-    case 5: rc = launch_gibbs<5>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, chain0, states, st); break;
-    case 6: rc = launch_gibbs<6>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, chain0, states, st); break;
-    case 7: case 8: rc = launch_gibbs<8>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, chain0, states, st); break;
-    default: rc = launch_gibbs<16>(lin, J, B, R, n, sweeps, beta0, beta1, seed, offset, chain0, states, st); break;
+    case 1: rc = launch_gibbs<1>(lin, J, B, R, n, sweeps, beta0, beta1, beta_dev, seed, offset, chain0, states, st); break;
+    case 2: rc = launch_gibbs<2>(lin, J, B, R, n, sweeps, beta0, beta1, beta_dev, seed, offset, chain0, states, st); break;
+    case 3: rc = launch_gibbs<3>(lin, J, B, R, n, sweeps, beta0, beta1, beta_dev, seed, offset, chain0, states, st); break;
+    case 4: rc = launch_gibbs<4>(lin, J, B, R, n, sweeps, beta0, beta1, beta_dev, seed, offset, chain0, states, st); break;
+    case 5: rc = launch_gibbs<5>(lin, J, B, R, n, sweeps, beta0, beta1, beta_dev, seed, offset, chain0, states, st); break;
+    case 6: rc = launch_gibbs<6>(lin, J, B, R, n, sweeps, beta0, beta1, beta_dev, seed, offset, chain0, states, st); break;
+    case 7: case 8: rc = launch_gibbs<8>(lin, J, B, R, n, sweeps, beta0, beta1, beta_dev, seed, offset, chain0, states, st); break;
+    default: rc = launch_gibbs<16>(lin, J, B, R, n, sweeps, beta0, beta1, beta_dev, seed, offset, chain0, states, st); break;
     }
     if (rc) return rc;
     if (mean) {
@@ -377,6 +516,72 @@ int qbm_qbm_batch_stats(const double* X, const int32_t* labels, const double* me
     return QBM_OK;
 }
 
+int qbm_qbm_couplings(const double* w_label, const double* W_hh, int H, int clamped, double beta_eff, float* J,
+                      double* rowabs, double* rowmin, void* stream)
+{
+    if (H <= 0) return fail(QBM_ERR_ARG, "couplings: H <= 0");
+    if (!J || !rowabs || !rowmin || (!clamped && !w_label)) return fail(QBM_ERR_ARG, "couplings: null buffer");
+    if (beta_eff == 0.0) return fail(QBM_ERR_ARG, "couplings: beta_eff == 0");
+    const int n = clamped ? H : H + 1;
+    hipLaunchKernelGGL(k_qbm_couplings, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_label, W_hh, H, clamped,
+                       beta_eff, J, rowabs, rowmin);
+    QBM_CHECK_LAUNCH("k_qbm_couplings");
+    return QBM_OK;
+}
+
+int qbm_qbm_beta_range(const float* lin, const double* rowabs, const double* rowmin, int B, int n, float* beta, void* stream)
+{
+    if (B < 0 || n <= 0) return fail(QBM_ERR_ARG, "beta_range: bad dims");
+    if (B == 0) return QBM_OK;
+    if (!lin || !rowabs || !rowmin || !beta) return fail(QBM_ERR_ARG, "beta_range: null buffer");
+    hipLaunchKernelGGL(k_qbm_beta, dim3(B), dim3(64), 0, (hipStream_t)stream, lin, rowabs, rowmin, B, n, beta);
+    QBM_CHECK_LAUNCH("k_qbm_beta");
+    return QBM_OK;
+}
+
+int qbm_qbm_stats_diff(const double* X, const int32_t* labels, const double* mean_c, const double* mean_u, int B, int D,
+                       int H, double* diff, void* stream)
+{
+    if (B < 0) return fail(QBM_ERR_ARG, "stats_diff: B < 0");
+    if (D <= 0 || H <= 0) return fail(QBM_ERR_ARG, "stats_diff: non-positive dims");
+    if (!diff || (B > 0 && (!X || !labels || !mean_c || !mean_u))) return fail(QBM_ERR_ARG, "stats_diff: null buffer");
+    const long total = qbm_theta_len(D, H);
+    hipLaunchKernelGGL(k_qbm_stats_diff, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, labels,
+                       mean_c, mean_u, B, D, H, diff);
+    QBM_CHECK_LAUNCH("k_qbm_stats_diff");
+    return QBM_OK;
+}
+
+int qbm_qbm_apply_update(double* theta, const double* diff, int D, int H, double lr, double batch, void* stream)
+{
+    if (D <= 0 || H <= 0) return fail(QBM_ERR_ARG, "apply_update: non-positive dims");
+    if (!theta || !diff) return fail(QBM_ERR_ARG, "apply_update: null buffer");
+    if (!(batch > 0.0)) return fail(QBM_ERR_ARG, "apply_update: batch must be positive");
+    const long total = qbm_theta_len(D, H);
+    hipLaunchKernelGGL(k_qbm_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, theta, diff, total,
+                       lr, batch);
+    QBM_CHECK_LAUNCH("k_qbm_apply");
+    return QBM_OK;
+}
+
+int qbm_qbm_linear_fields_dev(const double* X, const int32_t* labels, const double* theta, int B, int D, int H,
+                              double beta_eff, float* lin, void* stream)
+{
+    if (B < 0) return fail(QBM_ERR_ARG, "linear_fields: B < 0");
+    if (B == 0) return QBM_OK;
+    if (D <= 0 || H <= 0) return fail(QBM_ERR_ARG, "linear_fields: non-positive dims");
+    if (!X || !theta || !lin) return fail(QBM_ERR_ARG, "linear_fields: null buffer");
+    if (beta_eff == 0.0) return fail(QBM_ERR_ARG, "linear_fields: beta_eff == 0");
+    const double* W_vh = theta;
+    const double* W_vo = W_vh + (long)(1 + D) * H;
+    const double* b_h = W_vo + D;
+    const int n = labels ? H : H + 1;
+    hipLaunchKernelGGL(k_linear_fields, dim3((B * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, X, labels, W_vh,
+                       W_vo, b_h, 0.0, b_h + H, B, D, H, beta_eff, lin);
+    QBM_CHECK_LAUNCH("k_linear_fields");
+    return QBM_OK;
+}
+
 int qbm_qbm_linear_fields(const double* X, const int32_t* labels, const double* W_vh, const double* W_vo,
                           const double* b_h, double b_o, int B, int D, int H, double beta_eff, float* lin,
                           void* stream)
@@ -388,7 +593,7 @@ int qbm_qbm_linear_fields(const double* X, const int32_t* labels, const double* 
     if (beta_eff == 0.0) return fail(QBM_ERR_ARG, "linear_fields: beta_eff == 0");
     const int n = labels ? H : H + 1;
     hipLaunchKernelGGL(k_linear_fields, dim3((B * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, X, labels, W_vh,
-                       W_vo, b_h, b_o, B, D, H, beta_eff, lin);
+                       W_vo, b_h, b_o, (const double*)nullptr, B, D, H, beta_eff, lin);
     QBM_CHECK_LAUNCH("k_linear_fields");
     return QBM_OK;
 }

@@ -7,9 +7,16 @@ order, QUBO construction, the statistics / update rule including its quirks (SUR
 layout of the visible-to-hidden statistics, Q8 hidden-hidden weights never learn), NLL, predict, the epoch
 loop with its per-epoch weight pickle and dump-on-exception.  What differs, deliberately:
   * `solver="HIP"` (default; "SA" is accepted as an alias): all images of a minibatch and all reads are
-    sampled in ONE kernel launch per phase, statistics are reduced on the device; the list-of-dicts sample
-    format of the reference is only materialised by the compatibility methods get_samples /
-    get_samples_batch;
+    sampled in ONE kernel launch per phase;
+  * the learned parameters live ON THE DEVICE during training (one float64 buffer
+    theta = [W_vh | W_vo | b_h | b_o], include/qbm_hip.h): fields, couplings, annealing range, sampling,
+    statistics and the update all run there, nothing crosses PCIe per minibatch.  The public numpy attributes
+    (`weights_all_visible_to_hidden`, ...) are views of the host copy, refreshed from the device when read and
+    uploaded when assigned (modify them by assignment, not in place, while a model is training);
+  * the annealing range is derived PER IMAGE from its QUBO's coefficients (qbm_qbm_beta_range), as the
+    reference's annealer does per QUBO; `beta_range=(b, b)` gives plain Gibbs sampling at inverse temperature b;
+  * the list-of-dicts sample format of the reference is only materialised by the compatibility methods
+    get_samples / get_samples_batch;
   * no D-Wave token is read or printed (Q13), no process pool (Q10), `restricted=True` works (Q9);
   * QPU / embedding methods are out of scope.
 There is no CPU fallback: sampling without the HIP library or a GPU raises QbmHipError."""
@@ -43,20 +50,19 @@ class Disc_QBM:
         self.parallelize = parallelize          # accepted for signature parity; the HIP path is always batched
         self.use_one_hot_encoding = use_one_hot_encoding
         self.n_output_nodes = 1
+        self._theta = None                      # device master of the learned parameters (float64, flat)
+        self._host_newer = True                 # the host copy has changes the device buffer lacks
+        self._dev_newer = False                 # ... and the other way round
+        self._whh_dev = None
+        self._J_cache = {}
         # RNG order of the reference (:82-87): W_hh from the CURRENT global numpy state, then reseed and draw
         # W_vh, W_vo, W_oo, b_h, b_o
         if not restricted:
             self.weights_hidden_hidden = self.init_weights_hidden_hidden()
         else:
             self.weights_hidden_hidden = None
-        (self.weights_all_visible_to_hidden, self.weights_clamped_visible_to_output, self.weights_output_output,
-         self.biases_hidden, self.biases_output) = self.init_weights_for_supervised()
+        (self._wvh, self._wvo, self.weights_output_output, self._bh, self._bo) = self.init_weights_for_supervised()
         self.param_string = param_string
-        self.weight_objects = [
-            self.weights_all_visible_to_hidden, self.weights_clamped_visible_to_output,
-            self.biases_hidden, self.biases_output,
-            self.weights_output_output, self.weights_hidden_hidden if self.weights_hidden_hidden is not None else None
-        ]
         if solver not in ("HIP", "SA"):
             # the reference's message for an unknown solver string (:681-682)
             raise Exception('No valid solver specified. This build samples on the GPU: use solver="HIP" '
@@ -66,7 +72,7 @@ class Disc_QBM:
         self.anneal_steps = anneal_steps
         self.sample_count = sample_count
         self.beta_eff = beta_eff
-        self.beta_range = beta_range            # None: derived per minibatch from the QUBO coefficients
+        self.beta_range = beta_range            # None: per image, from its QUBO's coefficients (qbm_qbm_beta_range)
         self._device = device
         self._ops = ops
         self._draw_offset = 0
@@ -76,6 +82,56 @@ class Disc_QBM:
         if load_path != "":
             self.load_savepoint(load_path)
         self.speicherort = speicherort
+
+    # ---- learned parameters: host copy <-> device master ------------------------------------------
+    def _get(self, name):
+        self._pull()
+        return getattr(self, name)
+
+    def _set(self, name, value):
+        self._pull()
+        setattr(self, name, np.asarray(value, dtype=np.float64))
+        self._host_newer = True
+
+    weights_all_visible_to_hidden = property(lambda s: s._get("_wvh"), lambda s, v: s._set("_wvh", v))          # [(1+D), H]
+    weights_clamped_visible_to_output = property(lambda s: s._get("_wvo"), lambda s, v: s._set("_wvo", v))      # [D, 1]
+    biases_hidden = property(lambda s: s._get("_bh"), lambda s, v: s._set("_bh", v))                            # [H]
+    biases_output = property(lambda s: s._get("_bo"), lambda s, v: s._set("_bo", v))                            # [1]
+
+    @property
+    def weight_objects(self):
+        """The reference's pickle layout (:88-95), built from the CURRENT arrays (the reference builds the list once, so a
+        savepoint loaded afterwards is not in it: ADVICE round 1)."""
+        return [self.weights_all_visible_to_hidden, self.weights_clamped_visible_to_output, self.biases_hidden,
+                self.biases_output, self.weights_output_output, self.weights_hidden_hidden]
+
+    def _theta_len(self):
+        D, H = self.dim_input, self.n_hidden_nodes
+        return (1 + D) * H + D + H + 1
+
+    def _push(self):
+        """Host copy -> device buffer (when the host copy is the newer one)."""
+        import torch
+
+        if self._theta is not None and not self._host_newer:
+            return
+        flat = np.concatenate([self._wvh.reshape(-1), self._wvo.reshape(-1), self._bh.reshape(-1), self._bo.reshape(-1)])
+        assert flat.size == self._theta_len()
+        self._theta = torch.from_numpy(np.ascontiguousarray(flat, dtype=np.float64)).to(self.ops.device)
+        self._host_newer, self._dev_newer = False, False
+        self._J_cache.pop(False, None)        # the unclamped couplings hold the label row of W_vh
+
+    def _pull(self):
+        """Device buffer -> host copy, in place (when the device holds updates the host copy lacks)."""
+        if not self._dev_newer:
+            return
+        self._dev_newer = False
+        flat = self._theta.detach().cpu().numpy()
+        D, H = self.dim_input, self.n_hidden_nodes
+        o = 0
+        for arr in (self._wvh, self._wvo, self._bh, self._bo):
+            arr[...] = flat[o:o + arr.size].reshape(arr.shape)
+            o += arr.size
 
     # ------------------------------------------------------------------------------------------
     @property
@@ -94,12 +150,12 @@ class Disc_QBM:
         with open(savepoint, "rb") as file:
             loaded = pickle.load(file)   # a file this class wrote (save_weights)
         assert len(loaded) in [5, 6]
+        (self.weights_all_visible_to_hidden, self.weights_clamped_visible_to_output, self.biases_hidden,
+         self.biases_output, self.weights_output_output) = loaded[:5]
         if len(loaded) == 6:
-            (self.weights_all_visible_to_hidden, self.weights_clamped_visible_to_output, self.biases_hidden,
-             self.biases_output, self.weights_output_output, self.weights_hidden_hidden) = loaded
-        else:
-            (self.weights_all_visible_to_hidden, self.weights_clamped_visible_to_output, self.biases_hidden,
-             self.biases_output, self.weights_output_output) = loaded
+            self.weights_hidden_hidden = loaded[5]
+            self._whh_dev = None
+            self._J_cache.clear()
 
     def init_weights_for_supervised(self):
         """src/model/faster_dqbm.py:192-218"""
@@ -120,24 +176,26 @@ class Disc_QBM:
         """src/model/faster_dqbm.py:225-284 (host numpy, for API parity and tests; the training path builds
         only the x-dependent diagonal, on the device)."""
         H, no = self.n_hidden_nodes, self.n_output_nodes
+        w_vh, w_vo = self.weights_all_visible_to_hidden, self.weights_clamped_visible_to_output
         if label is not None:
             visible = np.concatenate((np.array([label]), input_vector), axis=0)
-            q = np.diag(self.biases_hidden) + np.diag(np.matmul(visible, self.weights_all_visible_to_hidden).flatten())
+            q = np.diag(self.biases_hidden) + np.diag(np.matmul(visible, w_vh).flatten())
             if not self.restricted:
                 q = q + self.weights_hidden_hidden
             return q / self.beta_eff
         upper = np.zeros((no + H, no + H))
-        upper += np.pad(self.weights_all_visible_to_hidden[0:no, :], ((0, H), (no, 0)), 'constant', constant_values=0)
+        upper += np.pad(w_vh[0:no, :], ((0, H), (no, 0)), 'constant', constant_values=0)
         upper += np.pad(self.weights_output_output, ((0, H), (0, H)), 'constant', constant_values=0)
         if not self.restricted:
             upper[no:, no:] += self.weights_hidden_hidden
         biases = np.concatenate((self.biases_output, self.biases_hidden), axis=0)
-        w_in = np.concatenate((self.weights_clamped_visible_to_output, self.weights_all_visible_to_hidden[no:, :]), axis=1)
+        w_in = np.concatenate((w_vo, w_vh[no:, :]), axis=1)
         return (np.diag(biases) + np.diag(np.matmul(input_vector, w_in).flatten()) + upper) / self.beta_eff
 
     # ---- HIP sampling -------------------------------------------------------------------------
     def _couplings(self, clamped: bool) -> np.ndarray:
-        """Image-independent symmetric couplings J (zero diagonal) of the QUBO (:242-243, :256-271)."""
+        """Image-independent symmetric couplings J (zero diagonal) of the QUBO (:242-243, :256-271), host statement
+        (the training path builds the same matrix on the device: qbm_qbm_couplings)."""
         H = self.n_hidden_nodes
         n, o = (H, 0) if clamped else (H + 1, 1)
         J = np.zeros((n, n), np.float32)
@@ -149,6 +207,21 @@ class Disc_QBM:
             whh = np.triu(self.weights_hidden_hidden, k=1) / self.beta_eff
             J[o:, o:] += (whh + whh.T).astype(np.float32)
         return J
+
+    def _couplings_dev(self, clamped: bool):
+        """(J, rowabs, rowmin) on the device.  The clamped couplings are W_hh only: built once; the unclamped ones hold the
+        label row of W_vh: rebuilt whenever theta has changed."""
+        import torch
+
+        self._push()
+        hit = self._J_cache.get(clamped)
+        if hit is not None:
+            return hit
+        if self._whh_dev is None and not self.restricted:
+            self._whh_dev = torch.from_numpy(np.ascontiguousarray(self.weights_hidden_hidden, dtype=np.float64)).to(self.ops.device)
+        out = self.ops.couplings(self._theta, self._whh_dev, self.n_hidden_nodes, clamped, self.beta_eff)
+        self._J_cache[clamped] = out
+        return out
 
     def _dp_group(self):
         """(rank, world) of the data-parallel group, (0, 1) when not distributed."""
@@ -167,37 +240,53 @@ class Disc_QBM:
         per = (n_rows + world - 1) // world
         return min(rank * per, n_rows), min((rank + 1) * per, n_rows)
 
+    def _to_dev(self, x_batch, y_batch):
+        """(X float64 [B,D], labels int32 [B] or None) on the sampler's device; device tensors pass through."""
+        import torch
+
+        dev = self.ops.device
+        if torch.is_tensor(x_batch):
+            X = x_batch.to(dev, torch.float64).reshape(x_batch.shape[0], self.dim_input).contiguous()
+        else:
+            X = torch.from_numpy(np.ascontiguousarray(np.asarray(x_batch, dtype=np.float64).reshape(len(x_batch), self.dim_input))).to(dev)
+        if y_batch is None:
+            return X, None
+        if torch.is_tensor(y_batch):
+            return X, y_batch.to(dev, torch.int32).reshape(-1).contiguous()
+        return X, torch.from_numpy(np.asarray(y_batch).reshape(-1).astype(np.int32)).to(dev)
+
     def sample_batch(self, x_batch, y_batch=None, rows=None):
         """Both the reference's get_samples_batch (:961-969) and the reduction over reads of
         get_average_configuration_batch (:777-780) for a whole minibatch, on the device:
         -> (states uint8 [B,R,n], mean float64 [B,n])  (device tensors).
-        rows=(lo, hi): sample only these images of the minibatch (one rank's shard).  The annealing range still comes
-        from the whole minibatch and the Philox rows are the global chain indices, so the shard's samples are exactly
-        the rows [lo, hi) of the unsharded call."""
+        rows=(lo, hi): sample only these images of the minibatch (one rank's shard).  The annealing range is per image and
+        the Philox rows are the global chain indices, so the shard's samples are exactly the rows [lo, hi) of the unsharded
+        call."""
         import torch
 
-        from .sampler import auto_beta_range
-
-        X = np.ascontiguousarray(np.asarray(x_batch, dtype=np.float64).reshape(len(x_batch), self.dim_input))
-        labels = None if y_batch is None else np.asarray(y_batch).reshape(-1).astype(np.int32)
-        lin = self.ops.linear_fields(X, labels, self.weights_all_visible_to_hidden,
-                                     self.weights_clamped_visible_to_output, self.biases_hidden, self.biases_output,
-                                     self.beta_eff)
-        J = self._couplings(clamped=labels is not None)
-        if self.beta_range is not None:
-            b0, b1 = self.beta_range
-        else:
-            b0, b1 = auto_beta_range(lin.cpu().numpy(), J)
+        X, labels = self._to_dev(x_batch, y_batch)
+        lo, hi = (0, X.shape[0]) if rows is None else rows
         offset = self._draw_offset
         self._draw_offset += int(self.anneal_steps) + 1
-        lo, hi = (0, len(X)) if rows is None else rows
-        n = lin.shape[1]
+        clamped = labels is not None
+        H = self.n_hidden_nodes
+        n = H if clamped else H + 1
         if hi <= lo:
-            dev = lin.device
+            dev = self.ops.device
             return (torch.empty(0, int(self.sample_count), n, dtype=torch.uint8, device=dev),
                     torch.empty(0, n, dtype=torch.float64, device=dev))
-        return self.ops.gibbs(lin[lo:hi].contiguous(), torch.from_numpy(J), int(self.sample_count), int(self.anneal_steps),
-                              b0, b1, int(self.seed), offset, True, lo * int(self.sample_count))
+        self._push()
+        Xs = X[lo:hi]
+        ls = None if labels is None else labels[lo:hi]
+        lin = self.ops.linear_fields_dev(Xs, ls, self._theta, self.dim_input, H, self.beta_eff)
+        J, rowabs, rowmin = self._couplings_dev(clamped)
+        if self.beta_range is not None:
+            beta = torch.tensor([float(self.beta_range[0]), float(self.beta_range[1])], dtype=torch.float32,
+                                device=self.ops.device).repeat(hi - lo, 1).contiguous()
+        else:
+            beta = self.ops.beta_range(lin, rowabs, rowmin)
+        return self.ops.gibbs_dev(lin, J, int(self.sample_count), int(self.anneal_steps), beta, int(self.seed), offset,
+                                  lo * int(self.sample_count))
 
     @staticmethod
     def _to_dicts(states_row):
@@ -254,68 +343,50 @@ class Disc_QBM:
             total += float(-log_probs[int(y)])
         return total / len(p1)
 
+    @staticmethod
+    def _nll_sum(mean_u, labels):
+        """Sum over the images of compute_nll's per-image term (:986-991), as a float64 scalar on mean_u's device:
+        -log(float32([1 - p1, p1])[y] + 1e-12) with p1 = mean of the output node."""
+        import torch
+
+        p1 = mean_u[:, 0]
+        probs = torch.stack([1.0 - p1, p1], dim=1).to(torch.float32)
+        lp = torch.log(probs + 1e-12)
+        return (-lp.gather(1, labels.long().view(-1, 1))).double().sum()
+
+    def _step_device(self, X, labels, learning_rate):
+        """One training iteration with every array on the device (src/model/faster_dqbm.py:998-1064):
+        -> (error of the output bias, average NLL) as 0-dim float64 device tensors.  With a data-parallel group every rank
+        is handed the SAME minibatch, samples only its rows, and the statistics difference plus the NLL sum meet in ONE
+        float64 all-reduce; every replica then applies the same update."""
+        import torch
+
+        rank, world = self._dp_group()
+        B = X.shape[0]
+        lo, hi = self._shard(B, rank, world) if world > 1 else (0, B)
+        _, mean_c = self.sample_batch(X, labels, rows=(lo, hi))      # positive / clamped phase (:1007)
+        _, mean_u = self.sample_batch(X, rows=(lo, hi))              # negative / unclamped phase (:1011)
+        D, H = self.dim_input, self.n_hidden_nodes
+        buf = torch.zeros(self._theta_len() + 1, dtype=torch.float64, device=self.ops.device)   # [diff (theta layout) | NLL sum]
+        if hi > lo:
+            self.ops.stats_diff(X[lo:hi], labels[lo:hi], mean_c, mean_u, D, H, buf)
+            buf[-1] = self._nll_sum(mean_u, labels[lo:hi])
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        self._push()
+        self.ops.apply_update(self._theta, buf, D, H, learning_rate, float(B))   # theta -= lr * (diff / B) (:1023-1059)
+        self._dev_newer = True
+        self._J_cache.pop(False, None)                                            # the label row of W_vh has moved
+        # W_oo (empty triu for one output node) and W_hh statistics are identically zero in the reference (Q8)
+        return buf[-2] / B, buf[-1] / B
+
     def train_for_one_iteration(self, x_batch, y_batch, learning_rate, nll=None):
         """src/model/faster_dqbm.py:998-1064 -> (errors_biases_output, avg_batch_nll)"""
-        rank, world = self._dp_group()
-        if world > 1:
-            return self._train_for_one_iteration_dp(x_batch, y_batch, learning_rate, rank, world)
-        _, mean_c = self.sample_batch(x_batch, y_batch)      # positive / clamped phase (:1007)
-        _, mean_u = self.sample_batch(x_batch)               # negative / unclamped phase (:1011)
-        bh_c, bo_c, wvh_c, wvo_c, woo_c, whh_c = self._stats(mean_c, x_batch, y_batch)
-        bh_u, bo_u, wvh_u, wvo_u, woo_u, whh_u = self._stats(mean_u, x_batch, None)
-        B = np.asarray(x_batch).shape[0]
-        err_bo = (bo_c - bo_u) / B
-        err_bh = (bh_c - bh_u) / B
-        err_wvh = (wvh_c - wvh_u) / B
-        err_wvo = (wvo_c - wvo_u) / B
-        err_woo = (woo_c - woo_u) / B
-        self.biases_output -= learning_rate * err_bo
-        self.biases_hidden -= learning_rate * err_bh
-        self.weights_all_visible_to_hidden -= learning_rate * err_wvh
-        self.weights_clamped_visible_to_output -= learning_rate * err_wvo
-        self.weights_output_output -= learning_rate * err_woo
-        if not self.restricted:
-            self.weights_hidden_hidden -= learning_rate * ((whh_c - whh_u) / B)   # zeros: W_hh never learns (Q8)
-        avg_batch_loss = self.compute_nll(y_batch, mean_u)
-        self.training_history.nll_per_batch.append(avg_batch_loss)
-        return err_bo, avg_batch_loss
-
-    def _train_for_one_iteration_dp(self, x_batch, y_batch, learning_rate, rank, world):
-        """The same update with the images of the minibatch split over the ranks: every rank
-        is handed the SAME minibatch, samples only its rows, and the statistics of both phases (differences of sums
-        over images) plus the NLL sum meet in ONE float64 all-reduce; every replica then applies the same update."""
-        import torch
-        import torch.distributed as dist
-
-        X = np.asarray(x_batch)
-        Y = np.asarray(y_batch).reshape(-1)
-        B = X.shape[0]
-        lo, hi = self._shard(B, rank, world)
-        _, mean_c = self.sample_batch(X, Y, rows=(lo, hi))
-        _, mean_u = self.sample_batch(X, rows=(lo, hi))
-        H, D = self.n_hidden_nodes, self.dim_input
-        flat = np.zeros(H + 1 + (1 + D) * H + D + 1, np.float64)   # [b_h | b_o | W_vh | W_vo | nll sum]
-        if hi > lo:
-            bh_c, bo_c, wvh_c, wvo_c, _, _ = self._stats(mean_c, X[lo:hi], Y[lo:hi])
-            bh_u, bo_u, wvh_u, wvo_u, _, _ = self._stats(mean_u, X[lo:hi], None)
-            flat[:H] = bh_c - bh_u
-            flat[H] = float(np.asarray(bo_c - bo_u).reshape(-1)[0])
-            flat[H + 1:H + 1 + (1 + D) * H] = (wvh_c - wvh_u).reshape(-1)
-            flat[H + 1 + (1 + D) * H:-1] = (wvo_c - wvo_u).reshape(-1)
-            flat[-1] = self.compute_nll(Y[lo:hi], mean_u) * (hi - lo)
-        dev = mean_c.device if dist.get_backend() != "gloo" else torch.device("cpu")
-        t = torch.from_numpy(flat).to(dev)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        flat = t.cpu().numpy()
-        err_bh, err_bo = flat[:H] / B, np.array([flat[H] / B])
-        err_wvh = flat[H + 1:H + 1 + (1 + D) * H].reshape(1 + D, H) / B
-        err_wvo = flat[H + 1 + (1 + D) * H:-1].reshape(D, 1) / B
-        self.biases_output -= learning_rate * err_bo
-        self.biases_hidden -= learning_rate * err_bh
-        self.weights_all_visible_to_hidden -= learning_rate * err_wvh
-        self.weights_clamped_visible_to_output -= learning_rate * err_wvo
-        # W_oo (empty triu for one output node) and W_hh statistics are identically zero in the reference (Q8)
-        avg_batch_loss = float(flat[-1] / B)
+        X, labels = self._to_dev(x_batch, y_batch)
+        err_bo, avg_nll = self._step_device(X, labels, learning_rate)
+        err_bo, avg_batch_loss = np.array([float(err_bo)]), float(avg_nll)
         self.training_history.nll_per_batch.append(avg_batch_loss)
         return err_bo, avg_batch_loss
 
@@ -328,9 +399,26 @@ class Disc_QBM:
             pickle.dump(self.weight_objects, f)
 
     def predict_batch(self, X):
-        """predict (:1227-1241) for many images in one launch -> int array of rounded output means"""
-        _, mean = self.sample_batch(X)
-        return np.round(mean[:, 0].cpu().numpy()).astype(int)   # numpy rounds half to even, like the reference
+        """predict (:1227-1241) for many images in one launch -> int array of rounded output means.  With a data-parallel
+        group the images are split over the ranks and the predictions meet in one all-reduce."""
+        import torch
+
+        rank, world = self._dp_group()
+        Xd, _ = self._to_dev(X, None)
+        n = Xd.shape[0]
+        if world <= 1:
+            _, mean = self.sample_batch(Xd)
+            p1 = mean[:, 0]
+        else:
+            import torch.distributed as dist
+
+            lo, hi = self._shard(n, rank, world)
+            _, mean = self.sample_batch(Xd, rows=(lo, hi))
+            p1 = torch.zeros(n, dtype=torch.float64, device=self.ops.device)
+            if hi > lo:
+                p1[lo:hi] = mean[:, 0]
+            dist.all_reduce(p1, op=dist.ReduceOp.SUM)
+        return np.round(p1.cpu().numpy()).astype(int)   # numpy rounds half to even, like the reference
 
     def predict(self, data):
         """src/model/faster_dqbm.py:1227-1241 -> (rounded output, samples of the output node)"""
@@ -340,45 +428,57 @@ class Disc_QBM:
         return rounded[0], out.flatten()
 
     def train_model(self, train_X, train_Y, val_X, val_Y, batch_size=8, learning_rate=0.005):
-        """src/model/faster_dqbm.py:1079-1166"""
+        """src/model/faster_dqbm.py:1079-1166.  The training and validation sets are moved to the device once; a minibatch is
+        a slice of the resident set, and the per-batch error / NLL stay on the device until the end of the epoch (no host
+        synchronisation per minibatch).  Files are written by rank 0 only."""
+        rank, _ = self._dp_group()
         save_folder = (self.speicherort or "") + self.param_string
-        os.makedirs(save_folder, exist_ok=True)
+        if rank == 0:
+            os.makedirs(save_folder, exist_ok=True)
         print("Training with \n" f"batch size: {batch_size}\n", f"learning rate: {learning_rate}\n",
               f"hidden nodes: {self.n_hidden_nodes}\n", f"sample count: {self.sample_count}\n",
               f"beta eff: {self.beta_eff}\n")
-        train_Y = np.asarray(train_Y)
+        Xd, Yd = self._to_dev(train_X, np.asarray(train_Y))
+        Xv, _ = self._to_dev(val_X, None)
+        n_train = Xd.shape[0]
         for epoch in range(1, self.epochs + 1):
             batchnum = 1
-            num_batches = max(1, len(train_X) // batch_size)
-            epoch_errors = 0
-            epoch_nll = 0
-            for b in range(0, len(train_X), batch_size):
-                x_batch = train_X[b:b + batch_size]       # the last partial batch is kept (:1106-1111)
-                y_batch = train_Y[b:b + batch_size]
-                if len(x_batch) == 0:
+            num_batches = max(1, n_train // batch_size)
+            errs, nlls = [], []
+            for b in range(0, n_train, batch_size):
+                xb, yb = Xd[b:b + batch_size], Yd[b:b + batch_size]       # the last partial batch is kept (:1106-1111)
+                if xb.shape[0] == 0:
                     continue
                 try:
-                    err_bo, avg_nll = self.train_for_one_iteration(x_batch, y_batch, learning_rate)
-                    avg_err = np.mean(err_bo)
-                    epoch_errors += avg_err
-                    epoch_nll += avg_nll
-                    self.training_history.errors_per_batch.append(avg_err)
+                    err_bo, avg_nll = self._step_device(xb, yb, learning_rate)
+                    errs.append(err_bo)
+                    nlls.append(avg_nll)
                     batchnum += 1
                 except Exception:
                     # dump-on-exception, then re-raise (:1128-1132)
-                    self.save_weights(f'e{epoch}_b{batchnum}_{self.param_string}', save_folder)
-                    metrics.save_history(f"{save_folder}/", self.training_history)
+                    if rank == 0:
+                        self.save_weights(f'e{epoch}_b{batchnum}_{self.param_string}', save_folder)
+                        metrics.save_history(f"{save_folder}/", self.training_history)
                     raise
-            self.save_weights(f'e{epoch}_{self.param_string}', save_folder)
-            val_predictions = self.predict_batch(val_X)
+            import torch
+
+            errs_h = torch.stack(errs).cpu().tolist() if errs else []        # ONE synchronisation per epoch
+            nlls_h = torch.stack(nlls).cpu().tolist() if nlls else []
+            self.training_history.errors_per_batch.extend(errs_h)             # np.mean of a 1-element array = the element
+            self.training_history.nll_per_batch.extend(nlls_h)
+            epoch_errors, epoch_nll = float(np.sum(errs_h)), float(np.sum(nlls_h))
+            if rank == 0:
+                self.save_weights(f'e{epoch}_{self.param_string}', save_folder)
+            val_predictions = self.predict_batch(Xv)
             acc, _, _, _, auc = metrics.get_metrics(np.asarray(val_Y), val_predictions, ["0", "1"])
             self.training_history.acc_per_epoch.append(acc)
             self.training_history.auc_per_epoch.append(auc)
             self.training_history.combined_acc_auc_per_epoch.append(0.5 * acc + 0.5 * auc)
             self.training_history.error_per_epoch.append(epoch_errors / num_batches)
             self.training_history.nll_per_epoch.append(epoch_nll / num_batches)
-        for name, values in (("acc_per_epoch", self.training_history.acc_per_epoch),
-                             ("auc_per_epoch", self.training_history.auc_per_epoch),
-                             ("combined_acc_auc_per_epoch", self.training_history.combined_acc_auc_per_epoch)):
-            with open(f"{save_folder}/{name}{self.seed}.pkl", "wb") as f:
-                pickle.dump(values, f)
+        if rank == 0:
+            for name, values in (("acc_per_epoch", self.training_history.acc_per_epoch),
+                                 ("auc_per_epoch", self.training_history.auc_per_epoch),
+                                 ("combined_acc_auc_per_epoch", self.training_history.combined_acc_auc_per_epoch)):
+                with open(f"{save_folder}/{name}{self.seed}.pkl", "wb") as f:
+                    pickle.dump(values, f)

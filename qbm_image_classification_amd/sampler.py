@@ -39,6 +39,53 @@ class HipQuboOps:
                                          ptr(states), ptr(mean), current_stream()), "qbm_qubo_gibbs_ex")
         return states, mean
 
+    # ---- device-resident Disc_QBM state: theta = [W_vh (1+D)*H | W_vo D | b_h H | b_o 1] float64 (include/qbm_hip.h) ----
+    def linear_fields_dev(self, X, labels, theta, D, H, beta_eff=1.0):
+        """x-dependent QUBO diagonal with the parameters read from the device buffer theta -> lin fp32 [B,n]."""
+        B = X.shape[0]
+        n = H if labels is not None else H + 1
+        lin = torch.empty(B, n, dtype=torch.float32, device=self.device)
+        check(self.lib.qbm_qbm_linear_fields_dev(ptr(X), ptr(labels), ptr(theta), B, D, H, float(beta_eff), ptr(lin),
+                                                 current_stream()), "qbm_qbm_linear_fields_dev")
+        return lin
+
+    def couplings(self, theta, W_hh, H, clamped, beta_eff=1.0):
+        """-> (J fp32 [n,n], rowabs f64 [n], rowmin f64 [n]); W_hh: float64 [H,H] device tensor or None (restricted)."""
+        n = H if clamped else H + 1
+        J = torch.empty(n, n, dtype=torch.float32, device=self.device)
+        rowabs = torch.empty(n, dtype=torch.float64, device=self.device)
+        rowmin = torch.empty(n, dtype=torch.float64, device=self.device)
+        check(self.lib.qbm_qbm_couplings(ptr(theta), ptr(W_hh), H, int(bool(clamped)), float(beta_eff), ptr(J), ptr(rowabs),
+                                         ptr(rowmin), current_stream()), "qbm_qbm_couplings")   # W_vh row 0 = theta[:H]
+        return J, rowabs, rowmin
+
+    def beta_range(self, lin, rowabs, rowmin):
+        """Per-image annealing range -> beta fp32 [B,2] = (hot, cold), on the device."""
+        B, n = lin.shape
+        beta = torch.empty(B, 2, dtype=torch.float32, device=self.device)
+        check(self.lib.qbm_qbm_beta_range(ptr(lin), ptr(rowabs), ptr(rowmin), B, n, ptr(beta), current_stream()),
+              "qbm_qbm_beta_range")
+        return beta
+
+    def gibbs_dev(self, lin, J, reads, sweeps, beta, seed=0, offset=0, chain0=0):
+        """Like gibbs(), with the per-image range beta[B,2] read from device memory."""
+        B, n = lin.shape
+        states = torch.empty(B, reads, n, dtype=torch.uint8, device=self.device)
+        mean = torch.empty(B, n, dtype=torch.float64, device=self.device)
+        check(self.lib.qbm_qubo_gibbs_dev(ptr(lin), ptr(J), B, reads, n, sweeps, ptr(beta), 1.0, 1.0, seed, offset, int(chain0),
+                                          ptr(states), ptr(mean), current_stream()), "qbm_qubo_gibbs_dev")
+        return states, mean
+
+    def stats_diff(self, X, labels, mean_c, mean_u, D, H, out):
+        """out[theta layout] = statistics(clamped) - statistics(unclamped) of the images given."""
+        check(self.lib.qbm_qbm_stats_diff(ptr(X), ptr(labels), ptr(mean_c), ptr(mean_u), X.shape[0], D, H, ptr(out),
+                                          current_stream()), "qbm_qbm_stats_diff")
+        return out
+
+    def apply_update(self, theta, diff, D, H, lr, batch):
+        check(self.lib.qbm_qbm_apply_update(ptr(theta), ptr(diff), D, H, float(lr), float(batch), current_stream()),
+              "qbm_qbm_apply_update")
+
     def linear_fields(self, X, labels, W_vh, W_vo, b_h, b_o, beta_eff=1.0):
         """x-dependent QUBO diagonal of Disc_QBM.create_qubo_matrix_from (faster_dqbm.py:225-284), f64 in,
         fp32 [B,n] out on the device.  labels None = unclamped (n = 1+H), else clamped (n = H)."""

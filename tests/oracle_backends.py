@@ -38,6 +38,50 @@ class OracleQuboOps:
     def batch_stats(self, X, labels, mean, H):
         return tuple(torch.from_numpy(a) for a in orc.qbm_batch_stats(_np(X, np.float64), labels, _np(mean, np.float64), H))
 
+    # ---- device-resident parameter path (theta = [W_vh | W_vo | b_h | b_o], include/qbm_hip.h) on CPU tensors ----
+    @staticmethod
+    def _split(theta, D, H):
+        t = _np(theta, np.float64)
+        o = (1 + D) * H
+        return t[:o].reshape(1 + D, H), t[o:o + D], t[o + D:o + D + H], t[o + D + H:o + D + H + 1]
+
+    def linear_fields_dev(self, X, labels, theta, D, H, beta_eff=1.0):
+        W_vh, W_vo, b_h, b_o = self._split(theta, D, H)
+        lab = None if labels is None else _np(labels, np.int32)
+        return torch.from_numpy(orc.qbm_linear_fields(_np(X, np.float64), lab, W_vh, W_vo, b_h, b_o, beta_eff))
+
+    def couplings(self, theta, W_hh, H, clamped, beta_eff=1.0):
+        w_label = _np(theta, np.float64)[:H].reshape(1, H)            # W_vh row 0
+        J = orc.qbm_couplings(w_label, None if W_hh is None else _np(W_hh, np.float64), bool(clamped), beta_eff)
+        rowabs, rowmin = orc.qbm_coupling_stats(J)
+        return torch.from_numpy(J), torch.from_numpy(rowabs), torch.from_numpy(rowmin)
+
+    def beta_range(self, lin, rowabs, rowmin):
+        return torch.from_numpy(orc.qbm_beta_range(_np(lin), _np(rowabs, np.float64), _np(rowmin, np.float64)))
+
+    def gibbs_dev(self, lin, J, reads, sweeps, beta, seed=0, offset=0, chain0=0):
+        n = lin.shape[1]
+        if self.fixed is not None:
+            st = self.fixed[n]
+            return torch.from_numpy(st), torch.from_numpy(st.astype(np.float64).mean(axis=1))
+        lin, J, beta = _np(lin), _np(J), _np(beta)
+        states = np.empty((lin.shape[0], reads, n), np.uint8)
+        mean = np.empty((lin.shape[0], n), np.float64)
+        for b in range(lin.shape[0]):                                 # per-image annealing range: one oracle call per image
+            states[b:b + 1], mean[b:b + 1] = orc.qubo_gibbs(lin[b:b + 1], J, reads, sweeps, float(beta[b, 0]), float(beta[b, 1]),
+                                                            seed, offset, chain0 + b * reads)
+        return torch.from_numpy(states), torch.from_numpy(mean)
+
+    def stats_diff(self, X, labels, mean_c, mean_u, D, H, out):
+        d = orc.qbm_stats_diff(_np(X, np.float64), _np(labels, np.int32), _np(mean_c, np.float64), _np(mean_u, np.float64), H)
+        out[:d.size] = torch.from_numpy(d)
+        return out
+
+    def apply_update(self, theta, diff, D, H, lr, batch):
+        n = (1 + D) * H + D + H + 1
+        t, d = theta.numpy(), _np(diff, np.float64)
+        t[:n] = t[:n] - lr * (d[:n] / batch)
+
 
 class OracleRbmOps:
     """Stand-in for rbm_ops.HipRbmOps (CPU tensors in and out)."""

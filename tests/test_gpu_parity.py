@@ -502,3 +502,88 @@ def test_disc_qbm_trains_on_gpu(tmp_path):
     assert p in (0, 1) and outs.shape == (50,)
     s = q.get_samples(X[0], label=1)
     assert len(s) == 50 and set(s[0].keys()) == set(range(6))
+
+
+def test_qbm_device_state_kernels_bitwise(oracle):
+    """The kernels behind the device-resident Disc_QBM step (couplings + coefficient statistics, per-image annealing range,
+    statistics difference, update) against the oracle: float64 / fp32 values bit for bit."""
+    from qbm_image_classification_amd.sampler import HipQuboOps
+
+    q = HipQuboOps("cuda:0")
+    rs = np.random.RandomState(21)
+    for D, H, B, restricted, beta_eff in ((12, 5, 4, False, 0.7), (784, 256, 73, False, 1.0), (784, 33, 9, True, 2.0)):
+        n_theta = (1 + D) * H + D + H + 1
+        theta = rs.uniform(-1, 1, n_theta)
+        W_hh = None if restricted else np.triu(rs.uniform(-1, 1, (H, H)), 1)
+        X = (rs.random_sample((B, D)) < 0.2).astype(np.float64)
+        Y = rs.randint(0, 2, B).astype(np.int32)
+        t64 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+        th = t64(theta)
+        whh = None if W_hh is None else t64(W_hh)
+        W_vh = theta[:(1 + D) * H].reshape(1 + D, H)
+        for clamped in (True, False):
+            J, rowabs, rowmin = q.couplings(th, whh, H, clamped, beta_eff)
+            Jo = oracle.qbm_couplings(W_vh, W_hh, clamped, beta_eff)
+            ra, rm = oracle.qbm_coupling_stats(Jo)
+            assert np.array_equal(J.cpu().numpy(), Jo)
+            assert np.array_equal(rowabs.cpu().numpy(), ra) and np.array_equal(rowmin.cpu().numpy(), rm)
+            labels = torch.from_numpy(Y).cuda() if clamped else None
+            lin = q.linear_fields_dev(t64(X), labels, th, D, H, beta_eff)
+            W_vo, b_h, b_o = theta[(1 + D) * H:(1 + D) * H + D], theta[(1 + D) * H + D:-1], theta[-1:]
+            lo = oracle.qbm_linear_fields(X, Y if clamped else None, W_vh, W_vo, b_h, b_o, beta_eff)
+            assert np.array_equal(lin.cpu().numpy().view(np.uint32), lo.view(np.uint32))
+            beta = q.beta_range(lin, rowabs, rowmin)
+            bo = oracle.qbm_beta_range(lo, ra, rm)
+            assert np.array_equal(beta.cpu().numpy().view(np.uint32), bo.view(np.uint32)), (D, H, clamped)
+            if not restricted or not clamped:
+                assert (bo[:, 1] >= 10 * bo[:, 0] * (1 - 1e-6)).all() and (bo[:, 0] > 0).all()
+            R, sweeps = 6, 4
+            if D * H < 5000 or clamped:
+                st, mean = q.gibbs_dev(lin, J, R, sweeps, beta, 11, 3, 40)
+                for b in range(B):
+                    so, mo = oracle.qubo_gibbs(lo[b:b + 1], Jo, R, sweeps, float(bo[b, 0]), float(bo[b, 1]), 11, 3, 40 + b * R)
+                    assert np.array_equal(st[b:b + 1].cpu().numpy(), so) and np.array_equal(mean[b:b + 1].cpu().numpy(), mo)
+        mc = rs.randint(0, 11, (B, H)) / 10.0
+        mu = rs.randint(0, 11, (B, H + 1)) / 10.0
+        out = torch.zeros(n_theta + 1, dtype=torch.float64, device="cuda")
+        q.stats_diff(t64(X), torch.from_numpy(Y).cuda(), t64(mc), t64(mu), D, H, out)
+        want = oracle.qbm_stats_diff(X, Y, mc, mu, H)
+        assert np.array_equal(out[:-1].cpu().numpy(), want) and float(out[-1]) == 0.0
+        q.apply_update(th, out, D, H, 0.05, float(B))
+        assert np.array_equal(th.cpu().numpy(), theta - 0.05 * (want / float(B)))
+    # a QUBO without any coefficient: the fallback range
+    z = torch.zeros(2, 7, dtype=torch.float32, device="cuda")
+    zz = torch.zeros(7, dtype=torch.float64, device="cuda")
+    assert np.array_equal(q.beta_range(z, zz, zz).cpu().numpy(), np.array([[0.1, 1.0]] * 2, np.float32))
+
+
+def test_disc_qbm_device_step_equals_oracle_double(oracle):
+    """Disc_QBM.train_for_one_iteration with the parameters resident on the GPU (fields, couplings, annealing range, both
+    sampling phases, statistics, update: all kernels) against the same class driven by the oracle-backed double: every
+    parameter bit for bit after each of 3 iterations, on a 784-input model."""
+    from oracle_backends import OracleQuboOps
+    from qbm_image_classification_amd.disc_qbm import Disc_QBM
+    from qbm_image_classification_amd.sampler import HipQuboOps
+
+    rs = np.random.RandomState(5)
+    X = (rs.random_sample((10, 784)) < 0.15).astype(np.float64)
+    Y = rs.randint(0, 2, 10)
+
+    def make(ops):
+        np.random.seed(17)
+        return Disc_QBM(dim_input=784, num_classes=2, n_hidden_nodes=20, seed=9, solver="HIP", sample_count=8, anneal_steps=6,
+                        beta_eff=1.0, ops=ops, data_parallel=False)
+
+    g, o = make(HipQuboOps("cuda:0")), make(OracleQuboOps())
+    for it in range(3):
+        eg, ng = g.train_for_one_iteration(X, Y, 0.05)
+        eo, no = o.train_for_one_iteration(X, Y, 0.05)
+        assert np.array_equal(eg, eo) and abs(ng - no) <= 1e-6, it
+        for name in ("weights_all_visible_to_hidden", "weights_clamped_visible_to_output", "biases_hidden", "biases_output"):
+            assert np.array_equal(getattr(g, name), getattr(o, name)), (it, name)
+    assert np.array_equal(g.weights_hidden_hidden, o.weights_hidden_hidden)       # Q8: never learns
+    assert np.array_equal(g.predict_batch(X), o.predict_batch(X))
+    # assignment uploads: the next step starts from the assigned parameters on both sides
+    g.biases_hidden = np.zeros(20); o.biases_hidden = np.zeros(20)
+    g.train_for_one_iteration(X, Y, 0.05); o.train_for_one_iteration(X, Y, 0.05)
+    assert np.array_equal(g.biases_hidden, o.biases_hidden) and np.array_equal(g.weights_all_visible_to_hidden, o.weights_all_visible_to_hidden)
