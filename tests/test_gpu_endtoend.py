@@ -166,3 +166,22 @@ def test_reference_run_h20_seed_average_within_0p1_percent():
     assert abs(np.mean(aucs) - float(g["mean_final_auc"])) <= 1e-3
     assert exact >= 9
     assert abs(np.mean(accs) - float(g["published_acc"])) <= 0.03 and abs(np.mean(aucs) - float(g["published_auc"])) <= 0.03
+
+
+@pytest.mark.parametrize("beta1", [False, True])
+def test_config5_pipeline_coreset_mnist_qbm(beta1):
+    """BASELINE.json configs[4] as one thing (tools/qbm_pipeline.py): binarised MNIST 0/1 fixture -> hidden-mean embeddings
+    (sample_hidden kernel) -> k_center_greedy coreset of 256 images (GPU picks) -> Disc_QBM 784v / 256h trained for 4 epochs
+    with the HIP Gibbs sampler (annealed per-image range, and plain Gibbs at beta = 1 as north_star words it) -> accuracy on
+    515 held-out digits.  Measured on MI355X: 0.88 / 0.87 (majority class 0.52); bar 0.80.  The sampler replaces dwave-neal
+    (absent): parity with the reference's sampler is unpinned, this pins that the replacement LEARNS at the stated size."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
+    from qbm_pipeline import run
+
+    r = run(hidden=256, budget=256, epochs=4, reads=20, sweeps=20, lr=0.2, batch=32, beta1=beta1, seed=7)
+    print(r)
+    assert r["coreset"] == 256 and r["test_images"] == 515
+    assert r["test_acc"] >= 0.80 and r["coreset_acc"] >= 0.90, r
+    assert r["val_acc_per_epoch"][-1] > r["val_acc_per_epoch"][0]          # it learns over the epochs
