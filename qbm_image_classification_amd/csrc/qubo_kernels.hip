@@ -159,10 +159,9 @@ __device__ __forceinline__ void gibbs_chain(const float* __restrict__ lin, const
         }
 #pragma unroll
         for (int t = 0; t < NF; ++t) {
-            const int cnt = min(64, n - 64 * t);
-            if (cnt <= 0) break;
-            unsigned long long pending = (cnt >= 64) ? ~0ull : ((1ull << cnt) - 1ull);  // spins of this tile not yet visited
-            while (true) {
+            const int cnt = min(64, n - 64 * t);   // <= 0: a tile beyond n (no spin to visit: `pending` is empty)
+            unsigned long long pending = (cnt >= 64) ? ~0ull : (cnt <= 0 ? 0ull : ((1ull << cnt) - 1ull));  // spins of this tile not yet visited
+            while (pending) {
                 const bool ns = (beta * F[t]) < thr[t];
                 const unsigned long long want = __ballot(ns != st[t]) & pending;
                 if (want == 0ull) break;
@@ -432,7 +431,7 @@ int launch_gibbs(const float* lin, const float* J, int B, int R, int n, int swee
 {
     const int nch = B * R;
     const size_t tri_bytes = (size_t)n * (n + 1) / 2 * sizeof(float);
-    if (NF <= 5 && tri_bytes <= 150 * 1024 && nch >= 64) {
+    if constexpr (NF <= 5) if (tri_bytes <= 150 * 1024 && nch >= 64) {
         // the triangle of J fits the LDS of a CU (n <= 276): one persistent workgroup per CU, rows of J read from LDS
         if (tri_bytes > 65536) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_qubo_gibbs_lds<NF>),
@@ -493,6 +492,8 @@ int qbm_qubo_gibbs_dev(const float* lin, const float* J, int B, int R, int n, in
     case 5: rc = launch_gibbs<5>(lin, J, B, R, n, sweeps, beta0, beta1, beta_dev, seed, offset, chain0, states, st); break;
     case 6: rc = launch_gibbs<6>(lin, J, B, R, n, sweeps, beta0, beta1, beta_dev, seed, offset, chain0, states, st); break;
     case 7: case 8: rc = launch_gibbs<8>(lin, J, B, R, n, sweeps, beta0, beta1, beta_dev, seed, offset, chain0, states, st); break;
+    case 9: case 10: rc = launch_gibbs<10>(lin, J, B, R, n, sweeps, beta0, beta1, beta_dev, seed, offset, chain0, states, st); break;
+    case 11: case 12: rc = launch_gibbs<12>(lin, J, B, R, n, sweeps, beta0, beta1, beta_dev, seed, offset, chain0, states, st); break;   // conv-QBM QUBOs (n ~ 700)
     default: rc = launch_gibbs<16>(lin, J, B, R, n, sweeps, beta0, beta1, beta_dev, seed, offset, chain0, states, st); break;
     }
     if (rc) return rc;
