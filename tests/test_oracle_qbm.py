@@ -117,3 +117,26 @@ def test_gibbs_is_deterministic_and_offset_sensitive(oracle):
     c, _ = oracle.qubo_gibbs(lin, J, 64, 3, 1.0, 1.0, seed=1, offset=8)
     assert np.array_equal(a, b) and not np.array_equal(a, c)
     assert abs(a.mean() - 0.5) < 0.1   # zero fields: fair coins
+
+
+def test_oracle_anneal_on_reference_conv_qbm_qubo(oracle):
+    """The conv-QBM QUBO fixture (tools/make_golden_cdqbm.py, built by the imported reference's src/qubo/builder.py): upper
+    triangular, the penalty structure is where builder.py:116-146 puts it, and an oracle anneal satisfies the OR-link
+    constraints (the checker of the GPU test test_sample_q_on_reference_conv_qbm_qubo)."""
+    from qbm_image_classification_amd.sampler import auto_beta_range
+
+    g = golden("cdqbm_qubo.npz")
+    Q = g["Q_unclamped"][0]
+    n = Q.shape[0]
+    W, pool0, pen = g["pool_windows"], int(g["pool"][0]), float(g["penalty"])
+    assert n == 717 and not np.tril(Q, -1).any() and W.shape == (36, 16)
+    for k, w in enumerate(W):                                   # pairs inside a window: +penalty; unit <-> pool unit: -2 penalty
+        assert np.allclose(Q[np.ix_(w, w)][np.triu_indices(16, 1)], pen, atol=1e-6)
+        assert np.allclose(Q[w, pool0 + k], -2 * pen, atol=1e-6)
+    lin = np.diag(Q).astype(np.float32)[None, :]
+    off = Q - np.diag(np.diag(Q))
+    J = (off + off.T).astype(np.float32)
+    S, _ = oracle.qubo_gibbs(lin, J, 4, 1000, *auto_beta_range(lin, J), 5, 0)
+    S = S[0].astype(np.float64)
+    link = np.mean([[S[r, pool0 + k] == (S[r, w].sum() > 0) for k, w in enumerate(W)] for r in range(len(S))])
+    assert link >= 0.99
