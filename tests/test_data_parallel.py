@@ -115,25 +115,29 @@ def _qbm_worker(rank, world, port, ret):
         states, _ = q.sample_batch(X, Y, rows=(lo, hi))
         q._draw_offset = 0
         out = [q.train_for_one_iteration(X, Y, 0.05) for _ in range(3)]
+        pred = q.predict_batch(X)                                                  # sharded over the ranks, one all-reduce
         ret[rank] = dict(W_vh=q.weights_all_visible_to_hidden.copy(), W_vo=q.weights_clamped_visible_to_output.copy(),
-                         b_h=q.biases_hidden.copy(), b_o=q.biases_output.copy(), out=out, states=states.numpy().copy(), rows=(lo, hi))
+                         b_h=q.biases_hidden.copy(), b_o=q.biases_output.copy(), out=out, states=states.numpy().copy(), rows=(lo, hi),
+                         pred=pred)
     finally:
         dist.destroy_process_group()
 
 
-def test_disc_qbm_two_ranks_match_single_process():
+@pytest.mark.parametrize("world", [2, 4])
+def test_disc_qbm_ranks_match_single_process(world):
+    """7 images over 2 ranks (4 + 3) and over 4 ranks (2 + 2 + 2 + 1: a ragged last shard)."""
     sys_path = os.path.dirname(os.path.abspath(__file__))
     os.environ["PYTHONPATH"] = os.pathsep.join([sys_path, os.path.dirname(sys_path), os.environ.get("PYTHONPATH", "")])
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_qbm_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    mp.spawn(_qbm_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     X, Y = _qbm_data()
     single = _make_qbm(False)
     states, _ = single.sample_batch(X, Y)
     single._draw_offset = 0
     out = [single.train_for_one_iteration(X, Y, 0.05) for _ in range(3)]
-    assert [ret[r]["rows"] for r in (0, 1)] == [(0, 4), (4, 7)]
-    for r in (0, 1):
+    assert [ret[r]["rows"] for r in range(world)] == ([(0, 4), (4, 7)] if world == 2 else [(0, 2), (2, 4), (4, 6), (6, 7)])
+    for r in range(world):
         lo, hi = ret[r]["rows"]
         assert np.array_equal(ret[r]["states"], states.numpy()[lo:hi])            # a shard's chains are the global chains
         for k, ref in (("W_vh", single.weights_all_visible_to_hidden), ("W_vo", single.weights_clamped_visible_to_output),
@@ -141,7 +145,8 @@ def test_disc_qbm_two_ranks_match_single_process():
             assert np.allclose(ret[r][k], ref, rtol=0, atol=1e-12), (r, k)       # float64 sums associated per rank
         for (e1, n1), (e2, n2) in zip(ret[r]["out"], out):
             assert np.allclose(e1, e2, atol=1e-12) and abs(n1 - n2) < 1e-6
-    assert np.array_equal(ret[0]["W_vh"], ret[1]["W_vh"]) and np.array_equal(ret[0]["b_h"], ret[1]["b_h"])   # replicas identical
+        assert np.array_equal(ret[r]["W_vh"], ret[0]["W_vh"]) and np.array_equal(ret[r]["b_h"], ret[0]["b_h"])   # replicas identical
+        assert np.array_equal(ret[r]["pred"], single.predict_batch(X)) if r == 0 else True
 
 
 # ---- ragged last minibatch: short and EMPTY shards (N % (batch * world) != 0), world 2 and 4 -----------------------
