@@ -83,10 +83,14 @@ struct HiddenArgs {
     int ldsCls;    // byte offset of the per-wavefront class-term scratch (2 KiB each) in the dynamic LDS
 };
 
+// FAST (LDS-DMA path): 512 threads, strip_mma<SPLIT = 2> -- wavefronts 0..3 contract the first row tile of the strip,
+// wavefronts 4..7 the second, two wavefronts per SIMD -- and ONE output column per thread in the epilogue.
+// Otherwise (ragged / unaligned shapes, operands through registers): 256 threads, two columns per thread.
 template <class TA, bool FAST, int MODE, int CM>
-__global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
+__global__ __launch_bounds__(FAST ? 512 : 256) void k_hidden(HiddenArgs a)
 {
     constexpr int MT = H_MT, NT = H_NT;
+    constexpr int SPLIT = FAST ? 2 : 1, CP = FAST ? 1 : 2;   // wave groups; epilogue columns per thread
     extern __shared__ __attribute__((aligned(16))) char lds[];
     QBM_STAMP(10);
     // every kernel argument in ONE round trip to the (cold) scalar cache: the compiler otherwise fetches them where they
@@ -99,125 +103,123 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
     const int m0 = ms * 16 * MT, n0 = ns * 16 * NT;
     const typename KView<TA>::type A{reinterpret_cast<const TA*>(a.v), a.V, a.B};
     const ViewCContig Bv{a.W, a.H, a.H, a.V};
-    // Epilogue map: the 32 x 16 strip has 512 outputs = 2 consecutive columns for each of the 256 threads.
-    using SO = StripOut<MT, NT, 2>;
-    static_assert(SO::NP == 1, "one output pair per thread");
-    const int row = m0 + SO::row(0), j0 = n0 + 2 * SO::cg(0);
-    const int i_c = min(row, a.B - 1);
+    // Epilogue map: the 32 x 16 strip has 512 outputs: one per thread (FAST) or two consecutive columns per thread.
+    using SO = StripOut<MT, NT, CP, 256 * SPLIT>;
+    static_assert(SO::NP == 1, "one output (pair) per thread");
+    const int row = m0 + SO::row(0), j0 = n0 + CP * SO::cg(0);
+    const int i_c = min(row, a.B - 1), j_c = min(j0, a.H - 1), j_c1 = min(j0 + 1, a.H - 1);
     const bool with_cls = MODE == 0 && a.y != nullptr;
-    const bool pair = a.vecO && j0 + 1 < a.H;     // 8-byte accesses
-    // Everything of the epilogue that does not depend on the contraction -- bias and class-term loads, the class chain
-    // (classes c >= C enter it as fmaf(0, u, cls), which is exact), the Philox draw -- is taken out of the tail of the
-    // kernel AND out of its head: the loads are issued in `pre0` (unconditional, indices clamped, untracked by the
-    // compiler: gload_*), i.e. behind the first operand transfers of the contraction, and consumed in `pre`, while those
-    // transfers are in flight.
-    // Class term, FAST path: every vector-memory instruction of a wavefront costs the kernel's start as much as a 1 KiB
-    // operand transfer, so the 3*C loads per thread (y row, two U columns) are replaced by TWO LDS-DMA transfers per
-    // wavefront -- the 16-column tile of U (C x 64 B) and the y rows of its 8 strip rows (8 x 4C B, contiguous) -- into a
-    // 2 KiB scratch of its own, read back with ds_read in `pre`.
+    // Everything of the epilogue that does not depend on the contraction -- bias and class-term operands, the class chain
+    // (classes c >= C enter it as 0 * 0, which is exact), the Philox draw -- is taken out of the tail of the kernel AND out
+    // of its head: the operands are requested in `pre0`, i.e. behind the first operand transfers of the contraction, and
+    // consumed in `pre`, while those transfers are in flight.
+    //   FAST: untracked loads (gload_*: the compiler does not park the wave on them); a register written by one must reach
+    //         its consumer without a copy or a merge with another definition (the copy would run before the data arrives):
+    //         every such variable below has ONE definition.  Class term: every vector-memory instruction of a wavefront
+    //         costs the kernel's start about as much as a 1 KiB operand transfer, so instead of 2*C loads per thread TWO
+    //         LDS-DMA transfers per wavefront fetch the 16-column tile of U (C x 64 B) and the y rows of its 4 strip rows
+    //         (4 x 4C B, contiguous) into a 2 KiB scratch of its own, read back with ds_read (a.clsDma; else gload_*).
+    //   not FAST: ordinary loads, the compiler places the waits.
     const bool cls_dma = FAST && with_cls && a.clsDma;
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
     char* cls_lds = lds + a.ldsCls + wv * 2048;
-    // Three ways to the operands of the bias / class term, one per case, each with variables of its own: a register
-    // written by an untracked load (gload_*) must reach its consumer without passing through a copy or a merge with another
-    // definition -- the copy would run before the data has arrived.
-    //   pair, class term by LDS-DMA : d by gload_b64, U tile and y rows by two transfers, read back with ds_read in `pre`
-    //   pair                        : d, y, U by gload_* (untracked), consumed behind vm_wait in `pre`
-    //   not pair (ragged / unaligned columns): ordinary loads, the compiler places the waits
-    u32x2 d_a = {0u, 0u}, u_a[CM];
-    uint32_t y_a[CM];
+    uint32_t d_a = 0u, y_a[CM], u_a[CM];
     float d_g[2] = {0.f, 0.f}, y_g[CM], u_g[CM][2];
     auto pre0 = [&]() {
-        if (cls_dma) {   // by ALL lanes of the wavefront (a lane masked off would leave its chunk out)
-            // lanes 0..4C-1: 16-byte chunk (class = lane/4, columns n0 + 4*(lane%4) ..) of the U tile;
-            // lanes 0..2C-1: 16-byte chunk `lane` of the 8*C floats of rows m0 + 8*wv ..; everything else, and rows
-            // beyond the batch, read as zeros through the descriptors' range check
-            const rsrc_t ru = make_rsrc(a.U, (unsigned)(a.C * a.H * 4)), ry = make_rsrc(a.y, (unsigned)(a.B * a.C * 4));
-            blds16(ru, lane < 4 * a.C ? (unsigned)(((lane >> 2) * a.H + n0 + 4 * (lane & 3)) * 4) : kOOB, cls_lds);
-            blds16(ry, lane < 2 * a.C ? (unsigned)(((m0 + 8 * wv) * a.C + 4 * lane) * 4) : kOOB, cls_lds + 1024);
-        }
-        if (pair) {
-            gload_b64(d_a, a.d + j0);
+        if constexpr (FAST) {
+            if (cls_dma) {   // by ALL lanes of the wavefront (a lane masked off would leave its chunk out)
+                // lanes 0..4C-1: 16-byte chunk (class = lane/4, columns n0 + 4*(lane%4) ..) of the U tile;
+                // lanes 0..C-1: 16-byte chunk `lane` of the 4*C floats of rows m0 + 4*wv ..; everything else, and rows
+                // beyond the batch, read as zeros through the descriptors' range check
+                const rsrc_t ru = make_rsrc(a.U, (unsigned)(a.C * a.H * 4)), ry = make_rsrc(a.y, (unsigned)(a.B * a.C * 4));
+                blds16(ru, lane < 4 * a.C ? (unsigned)(((lane >> 2) * a.H + n0 + 4 * (lane & 3)) * 4) : kOOB, cls_lds);
+                blds16(ry, lane < a.C ? (unsigned)(((m0 + 4 * wv) * a.C + 4 * lane) * 4) : kOOB, cls_lds + 1024);
+            }
+            gload_b32(d_a, a.d + j_c);
             if (!cls_dma && with_cls) {
 #pragma unroll
                 for (int c = 0; c < CM; ++c) gload_b32(y_a[c], a.y + (long)i_c * a.C + min(c, a.C - 1));
 #pragma unroll
-                for (int c = 0; c < CM; ++c) gload_b64(u_a[c], a.U + (long)min(c, a.C - 1) * a.H + j0);
+                for (int c = 0; c < CM; ++c) gload_b32(u_a[c], a.U + (long)min(c, a.C - 1) * a.H + j_c);
             }
         } else {
-            d_g[0] = a.d[min(j0, a.H - 1)];
-            d_g[1] = a.d[min(j0 + 1, a.H - 1)];
+            d_g[0] = a.d[j_c];
+            d_g[1] = a.d[j_c1];
             if (with_cls) {
 #pragma unroll
                 for (int c = 0; c < CM; ++c) {
                     y_g[c] = a.y[(long)i_c * a.C + min(c, a.C - 1)];
-                    u_g[c][0] = a.U[(long)min(c, a.C - 1) * a.H + min(j0, a.H - 1)];
-                    u_g[c][1] = a.U[(long)min(c, a.C - 1) * a.H + min(j0 + 1, a.H - 1)];
+                    u_g[c][0] = a.U[(long)min(c, a.C - 1) * a.H + j_c];
+                    u_g[c][1] = a.U[(long)min(c, a.C - 1) * a.H + j_c1];
                 }
             }
         }
     };
-    float dv[2], cls[2] = {0.f, 0.f}, uu[2] = {0.f, 0.f};
+    float dv[2] = {0.f, 0.f}, cls[2] = {0.f, 0.f}, uu[2] = {0.f, 0.f};
     auto chain = [&](int c, float y, float u0, float u1) {   // class c of the class term (classes >= C enter as 0 * 0)
         const bool on = c < a.C;
         const float yv = on ? y : 0.f;
         cls[0] = __builtin_fmaf(yv, on ? u0 : 0.f, cls[0]);
-        cls[1] = __builtin_fmaf(yv, on ? u1 : 0.f, cls[1]);
+        if constexpr (CP == 2) cls[1] = __builtin_fmaf(yv, on ? u1 : 0.f, cls[1]);
     };
     auto pre = [&](int n_younger) {
         if (MODE == 0 && (a.s || a.s8)) {
-            // one Philox block serves columns 4*(j0>>2) .. +3; this thread's pair is its lower or upper half
+            // one Philox block serves columns 4*(j0>>2) .. +3
             uint32_t prow = a.row0 + (uint32_t)row;
             asm volatile("" : "+v"(prow));   // the draw depends on this statement's position: it cannot be hoisted above the transfers
             const f32x4 u4 = uniform4(a.seed, a.offset, prow, (uint32_t)(j0 >> 2));
-            uu[0] = (j0 & 2) ? u4[2] : u4[0];
-            uu[1] = (j0 & 2) ? u4[3] : u4[1];
+            if constexpr (CP == 1) {
+                const int e = j0 & 3;
+                uu[0] = e == 0 ? u4[0] : e == 1 ? u4[1] : e == 2 ? u4[2] : u4[3];
+            } else {
+                uu[0] = (j0 & 2) ? u4[2] : u4[0];
+                uu[1] = (j0 & 2) ? u4[3] : u4[1];
+            }
             asm volatile("" : "+v"(uu[0]), "+v"(uu[1]));   // ... nor sunk behind the wait below
         }
-        if (!pair) {
+        if constexpr (!FAST) {
             dv[0] = d_g[0]; dv[1] = d_g[1];
             if (with_cls) {
 #pragma unroll
                 for (int c = 0; c < CM; ++c) chain(c, y_g[c], u_g[c][0], u_g[c][1]);
             }
-            return;
-        }
-        vm_wait(n_younger);   // the loads / transfers of pre0 (and everything older) have landed; n_younger transfers stay in flight
-        asm volatile("" : "+v"(d_a));
-        dv[0] = __uint_as_float(d_a[0]); dv[1] = __uint_as_float(d_a[1]);
-        if (cls_dma) {
-            // this wavefront's own transfers: visible to its ds_reads behind the vm_wait above.  Row r of the wavefront
-            // (= lane/8) has its C floats at 1024 + 4*C*r; column pair (lane%8) of class c sits at 64*c + 8*(lane%8).
-            // Reads beyond class C-1 return whatever the scratch holds: masked in `chain`.
-            const uint32_t ya = lds_off(cls_lds) + 1024u + (uint32_t)(4 * a.C * (lane >> 3)), ua = lds_off(cls_lds) + 8u * (lane & 7);
-            uint32_t y_l[CM];
-            u32x2 u_l[CM];
+        } else {
+            vm_wait(n_younger);   // the loads / transfers of pre0 (and everything older) have landed; n_younger transfers stay in flight
+            asm volatile("" : "+v"(d_a));
+            dv[0] = __uint_as_float(d_a);
+            if (cls_dma) {
+                // this wavefront's own transfers: visible to its ds_reads behind the vm_wait above.  Row r of the wavefront
+                // (= lane/16) has its C floats at 1024 + 4*C*r; column (lane%16) of class c sits at 64*c + 4*(lane%16).
+                // Reads beyond class C-1 return whatever the scratch holds: masked in `chain`.
+                const uint32_t ya = lds_off(cls_lds) + 1024u + (uint32_t)(4 * a.C * (lane >> 4)), ua = lds_off(cls_lds) + 4u * (lane & 15);
+                uint32_t y_l[CM], u_l[CM];
 #pragma unroll
-            for (int c = 0; c < CM; ++c) {
-                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(y_l[c]) : "v"(ya), "n"(4 * c) : "memory");
-                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(u_l[c]) : "v"(ua), "n"(64 * c) : "memory");
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int c = 0; c < CM; ++c) {
+                    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(y_l[c]) : "v"(ya), "n"(4 * c) : "memory");
+                    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(u_l[c]) : "v"(ua), "n"(64 * c) : "memory");
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int c = 0; c < CM; ++c) {
-                asm volatile("" : "+v"(y_l[c]), "+v"(u_l[c]));
-                chain(c, __uint_as_float(y_l[c]), __uint_as_float(u_l[c][0]), __uint_as_float(u_l[c][1]));
-            }
-        } else if (with_cls) {
+                for (int c = 0; c < CM; ++c) {
+                    asm volatile("" : "+v"(y_l[c]), "+v"(u_l[c]));
+                    chain(c, __uint_as_float(y_l[c]), __uint_as_float(u_l[c]), 0.f);
+                }
+            } else if (with_cls) {
 #pragma unroll
-            for (int c = 0; c < CM; ++c) {
-                asm volatile("" : "+v"(y_a[c]), "+v"(u_a[c]));
-                chain(c, __uint_as_float(y_a[c]), __uint_as_float(u_a[c][0]), __uint_as_float(u_a[c][1]));
+                for (int c = 0; c < CM; ++c) {
+                    asm volatile("" : "+v"(y_a[c]), "+v"(u_a[c]));
+                    chain(c, __uint_as_float(y_a[c]), __uint_as_float(u_a[c]), 0.f);
+                }
             }
         }
     };
     QBM_STAMP(11);
-    const auto o = strip_mma<MT, NT, FAST, FAST, 2>(A, Bv, m0, n0, a.V, lds, a.KP, pre0, pre);
+    const auto o = strip_mma<MT, NT, FAST, FAST, CP, SPLIT>(A, Bv, m0, n0, a.V, lds, a.KP, pre0, pre);
     if (o.valid(0) && row < a.B && j0 < a.H) {
         const float sv[2] = {o.sum[0].x, o.sum[0].y};
         float pv[2], hv[2];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < CP; ++e) {
             float x = sv[e] + dv[e];
             if (MODE == 0) {
                 if (a.y) x = x + cls[e];
@@ -228,12 +230,12 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
             }
         }
         const long off = (long)row * a.H + j0;
-        if (pair) {
+        if (CP == 2 && a.vecO && j0 + 1 < a.H) {
             if (a.p) *reinterpret_cast<float2*>(a.p + off) = make_float2(pv[0], pv[1]);
             if (MODE == 0 && a.s) *reinterpret_cast<float2*>(a.s + off) = make_float2(hv[0], hv[1]);
             if (MODE == 0 && a.s8) *reinterpret_cast<uint16_t*>(a.s8 + off) = (uint16_t)((uint32_t)hv[0] | ((uint32_t)hv[1] << 8));
         } else {
-            for (int e = 0; e < 2 && j0 + e < a.H; ++e) {
+            for (int e = 0; e < CP && j0 + e < a.H; ++e) {
                 if (a.p) a.p[off + e] = pv[e];
                 if (MODE == 0 && a.s) a.s[off + e] = hv[e];
                 if (MODE == 0 && a.s8) a.s8[off + e] = (uint8_t)hv[e];
@@ -939,12 +941,12 @@ int launch_hidden_t(const qbm_rbm_params* P, const void* v, const float* y, int 
                aligned16(P->U) && small2g((long)B * P->C, 4) && small2g((long)P->C * P->H, 4);
     if (a.clsDma) {
         a.ldsCls = (int)lds;
-        lds += 4 * 2048;
+        lds += 8 * 2048;   // 2 KiB per wavefront of the 512-thread workgroup
     }
 #define QBM_LAUNCH(F, MODE, CM)                                                                  \
     {                                                                                            \
         if (int rc = set_lds(k_hidden<TA, F, MODE, CM>, lds)) return rc;                         \
-        hipLaunchKernelGGL((k_hidden<TA, F, MODE, CM>), dim3(nM * nN), dim3(256), lds, st, a);   \
+        hipLaunchKernelGGL((k_hidden<TA, F, MODE, CM>), dim3(nM * nN), dim3(F ? 512 : 256), lds, st, a); \
     }
     if (mode != 0 || !y) {  // no class term: the class-count bucket is irrelevant
         if (mode == 0) { if (fast) QBM_LAUNCH(true, 0, 2) else QBM_LAUNCH(false, 0, 2) }
