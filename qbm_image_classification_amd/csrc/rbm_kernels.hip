@@ -79,8 +79,8 @@ struct HiddenArgs {
     uint64_t seed, offset;
     uint32_t row0;
     bool vecO;
-    bool clsDma;   // the class-term operands (U tile, y rows) of a wavefront come by two LDS-DMA transfers
-    int ldsCls;    // byte offset of the per-wavefront class-term scratch (2 KiB each) in the dynamic LDS
+    bool epiDma;   // the epilogue operands (bias tile, U tile, y rows) of a wavefront come by LDS-DMA transfers
+    int ldsCls;    // byte offset of the per-wavefront scratch of those transfers (2 KiB each) in the dynamic LDS
 };
 
 // FAST (LDS-DMA path): 512 threads, strip_mma<SPLIT = 2> -- wavefronts 0..3 contract the first row tile of the strip,
@@ -113,34 +113,29 @@ __global__ __launch_bounds__(FAST ? 512 : 256) void k_hidden(HiddenArgs a)
     // (classes c >= C enter it as 0 * 0, which is exact), the Philox draw -- is taken out of the tail of the kernel AND out
     // of its head: the operands are requested in `pre0`, i.e. behind the first operand transfers of the contraction, and
     // consumed in `pre`, while those transfers are in flight.
-    //   FAST: untracked loads (gload_*: the compiler does not park the wave on them); a register written by one must reach
-    //         its consumer without a copy or a merge with another definition (the copy would run before the data arrives):
-    //         every such variable below has ONE definition.  Class term: every vector-memory instruction of a wavefront
-    //         costs the kernel's start about as much as a 1 KiB operand transfer, so instead of 2*C loads per thread TWO
-    //         LDS-DMA transfers per wavefront fetch the 16-column tile of U (C x 64 B) and the y rows of its 4 strip rows
-    //         (4 x 4C B, contiguous) into a 2 KiB scratch of its own, read back with ds_read (a.clsDma; else gload_*).
-    //   not FAST: ordinary loads, the compiler places the waits.
-    const bool cls_dma = FAST && with_cls && a.clsDma;
+    //   a.epiDma (FAST kernels, aligned operands): every vector-memory instruction of a wavefront costs the kernel's start
+    //       about as much as a 1 KiB operand transfer, so instead of 1 + 2*C loads per thread THREE LDS-DMA transfers per
+    //       wavefront fetch the bias tile (64 B), the 16-column tile of U (C x 64 B) and the y rows of its 4 strip rows
+    //       (4 x 4C B, contiguous) into a 2 KiB scratch of its own, read back with ds_read behind vm_wait.  (Loads into
+    //       registers that the compiler does not track are not an option here: it may copy their destination registers --
+    //       the hooks sit in the panel loop -- before the data has arrived.)
+    //   otherwise: ordinary loads, the compiler places the waits.
+    const bool with_dma = FAST && a.epiDma;
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
-    char* cls_lds = lds + a.ldsCls + wv * 2048;
-    uint32_t d_a = 0u, y_a[CM], u_a[CM];
+    char* cls_lds = lds + a.ldsCls + wv * 2048;   // [0, 1024) U tile, [1024, 1536) y rows, [1536, 1600) bias tile
     float d_g[2] = {0.f, 0.f}, y_g[CM], u_g[CM][2];
     auto pre0 = [&]() {
-        if constexpr (FAST) {
-            if (cls_dma) {   // by ALL lanes of the wavefront (a lane masked off would leave its chunk out)
-                // lanes 0..4C-1: 16-byte chunk (class = lane/4, columns n0 + 4*(lane%4) ..) of the U tile;
-                // lanes 0..C-1: 16-byte chunk `lane` of the 4*C floats of rows m0 + 4*wv ..; everything else, and rows
-                // beyond the batch, read as zeros through the descriptors' range check
+        if (with_dma) {   // by ALL lanes of the wavefront (a lane masked off would leave its chunk out)
+            // bias: lanes 0..3 = the four 16-byte chunks of d[n0 .. n0+15];
+            // U tile: lanes 0..4C-1: chunk (class = lane/4, columns n0 + 4*(lane%4) ..);
+            // y rows: lanes 0..C-1: chunk `lane` of the 4*C floats of rows m0 + 4*wv ..;
+            // everything else, and rows / columns beyond the operands, read as zeros through the descriptors' range check
+            const rsrc_t rd = make_rsrc(a.d, (unsigned)(a.H * 4));
+            blds16(rd, lane < 4 ? (unsigned)((n0 + 4 * lane) * 4) : kOOB, cls_lds + 1536 - 0);
+            if (with_cls) {
                 const rsrc_t ru = make_rsrc(a.U, (unsigned)(a.C * a.H * 4)), ry = make_rsrc(a.y, (unsigned)(a.B * a.C * 4));
                 blds16(ru, lane < 4 * a.C ? (unsigned)(((lane >> 2) * a.H + n0 + 4 * (lane & 3)) * 4) : kOOB, cls_lds);
                 blds16(ry, lane < a.C ? (unsigned)(((m0 + 4 * wv) * a.C + 4 * lane) * 4) : kOOB, cls_lds + 1024);
-            }
-            gload_b32(d_a, a.d + j_c);
-            if (!cls_dma && with_cls) {
-#pragma unroll
-                for (int c = 0; c < CM; ++c) gload_b32(y_a[c], a.y + (long)i_c * a.C + min(c, a.C - 1));
-#pragma unroll
-                for (int c = 0; c < CM; ++c) gload_b32(u_a[c], a.U + (long)min(c, a.C - 1) * a.H + j_c);
             }
         } else {
             d_g[0] = a.d[j_c];
@@ -177,38 +172,37 @@ __global__ __launch_bounds__(FAST ? 512 : 256) void k_hidden(HiddenArgs a)
             }
             asm volatile("" : "+v"(uu[0]), "+v"(uu[1]));   // ... nor sunk behind the wait below
         }
-        if constexpr (!FAST) {
+        if (!with_dma) {
             dv[0] = d_g[0]; dv[1] = d_g[1];
             if (with_cls) {
 #pragma unroll
                 for (int c = 0; c < CM; ++c) chain(c, y_g[c], u_g[c][0], u_g[c][1]);
             }
-        } else {
-            vm_wait(n_younger);   // the loads / transfers of pre0 (and everything older) have landed; n_younger transfers stay in flight
-            asm volatile("" : "+v"(d_a));
-            dv[0] = __uint_as_float(d_a);
-            if (cls_dma) {
-                // this wavefront's own transfers: visible to its ds_reads behind the vm_wait above.  Row r of the wavefront
-                // (= lane/16) has its C floats at 1024 + 4*C*r; column (lane%16) of class c sits at 64*c + 4*(lane%16).
-                // Reads beyond class C-1 return whatever the scratch holds: masked in `chain`.
-                const uint32_t ya = lds_off(cls_lds) + 1024u + (uint32_t)(4 * a.C * (lane >> 4)), ua = lds_off(cls_lds) + 4u * (lane & 15);
-                uint32_t y_l[CM], u_l[CM];
+            return;
+        }
+        if constexpr (CP == 1) {   // (with_dma implies the FAST kernel: one column per thread)
+            vm_wait(n_younger);   // this wavefront's transfers of pre0 (and everything older) have landed: visible to its ds_reads
+            // Row r of the wavefront (= lane/16) has its C floats at 1024 + 4*C*r; column (lane%16) of class c sits at
+            // 64*c + 4*(lane%16), its bias at 1536 + 4*(lane%16).  Reads beyond class C-1 return whatever the scratch holds:
+            // masked in `chain`.
+            const uint32_t ya = lds_off(cls_lds) + 1024u + (uint32_t)(4 * a.C * (lane >> 4)), ua = lds_off(cls_lds) + 4u * (lane & 15);
+            uint32_t d_l, y_l[CM], u_l[CM];
+            asm volatile("ds_read_b32 %0, %1 offset:1536" : "=v"(d_l) : "v"(ua) : "memory");
+            if (with_cls) {
 #pragma unroll
                 for (int c = 0; c < CM; ++c) {
                     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(y_l[c]) : "v"(ya), "n"(4 * c) : "memory");
                     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(u_l[c]) : "v"(ua), "n"(64 * c) : "memory");
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(d_l));
+            dv[0] = __uint_as_float(d_l);
+            if (with_cls) {
 #pragma unroll
                 for (int c = 0; c < CM; ++c) {
                     asm volatile("" : "+v"(y_l[c]), "+v"(u_l[c]));
                     chain(c, __uint_as_float(y_l[c]), __uint_as_float(u_l[c]), 0.f);
-                }
-            } else if (with_cls) {
-#pragma unroll
-                for (int c = 0; c < CM; ++c) {
-                    asm volatile("" : "+v"(y_a[c]), "+v"(u_a[c]));
-                    chain(c, __uint_as_float(y_a[c]), __uint_as_float(u_a[c]), 0.f);
                 }
             }
         }
@@ -935,11 +929,13 @@ int launch_hidden_t(const qbm_rbm_params* P, const void* v, const float* y, int 
                       small2g((long)B * P->V, ASZ) && small2g((long)P->V * P->H, 4);
     const int nM = (B + 16 * MT - 1) / (16 * MT), nN = (P->H + 16 * NT - 1) / (16 * NT);
     size_t lds = strip_lds_bytes<MT, NT, ASZ>(a.KP);
-    // class term by LDS-DMA: one transfer instruction must hold the U tile (4*C chunks of 16 B) and the 8 y rows of a
-    // wavefront (2*C chunks); whole, 16-byte aligned chunks only
-    a.clsDma = fast && mode == 0 && y && NT == 1 && MT == 2 && 4 * P->C <= 64 && ((long)B * P->C) % 4 == 0 && aligned16(y) &&
-               aligned16(P->U) && small2g((long)B * P->C, 4) && small2g((long)P->C * P->H, 4);
-    if (a.clsDma) {
+    // epilogue operands by LDS-DMA: one transfer instruction must hold the U tile (4*C chunks of 16 B), another the 4 y rows
+    // of a wavefront (C chunks); whole, 16-byte aligned chunks only
+    const bool cls = mode == 0 && y;
+    a.epiDma = fast && NT == 1 && MT == 2 && aligned16(P->d) &&
+               (!cls || (4 * P->C <= 64 && ((long)B * P->C) % 4 == 0 && aligned16(y) && aligned16(P->U) &&
+                         small2g((long)B * P->C, 4) && small2g((long)P->C * P->H, 4)));
+    if (a.epiDma) {
         a.ldsCls = (int)lds;
         lds += 8 * 2048;   // 2 KiB per wavefront of the 512-thread workgroup
     }

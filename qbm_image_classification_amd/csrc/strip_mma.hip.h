@@ -315,22 +315,6 @@ struct StripOut {
     __device__ __forceinline__ static int cg(int p) { return t(p) % kCG; }
 };
 
-// Loads whose consumer sits behind an explicit vm_wait(): the compiler's wait-count pass does not see them, so it
-// does not park the wave on them where they are issued.  The destination registers must not be touched before
-// that wait (tie them with `asm volatile("" : "+v"(x))` right behind it).
-__device__ __forceinline__ void gload_b32(uint32_t& dst, const void* p)
-{
-    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
-}
-__device__ __forceinline__ void gload_b64(u32x2& dst, const void* p)
-{
-    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
-}
-__device__ __forceinline__ void gload_b128(u32x4& dst, const void* p)
-{
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
-}
-
 // hook of strip_mma that does nothing
 struct NoPre {
     __device__ __forceinline__ void operator()() const {}
