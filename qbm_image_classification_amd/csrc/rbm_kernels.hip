@@ -83,14 +83,11 @@ struct HiddenArgs {
     int ldsCls;    // byte offset of the per-wavefront scratch of those transfers (2 KiB each) in the dynamic LDS
 };
 
-// FAST (LDS-DMA path): 512 threads, strip_mma<SPLIT = 2> -- wavefronts 0..3 contract the first row tile of the strip,
-// wavefronts 4..7 the second, two wavefronts per SIMD -- and ONE output column per thread in the epilogue.
-// Otherwise (ragged / unaligned shapes, operands through registers): 256 threads, two columns per thread.
 template <class TA, bool FAST, int MODE, int CM>
-__global__ __launch_bounds__(FAST ? 512 : 256) void k_hidden(HiddenArgs a)
+__global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
 {
     constexpr int MT = H_MT, NT = H_NT;
-    constexpr int SPLIT = FAST ? 2 : 1, CP = FAST ? 1 : 2;   // wave groups; epilogue columns per thread
+    constexpr int CP = 2;   // epilogue columns per thread
     extern __shared__ __attribute__((aligned(16))) char lds[];
     QBM_STAMP(10);
     // every kernel argument in ONE round trip to the (cold) scalar cache: the compiler otherwise fetches them where they
@@ -103,8 +100,8 @@ __global__ __launch_bounds__(FAST ? 512 : 256) void k_hidden(HiddenArgs a)
     const int m0 = ms * 16 * MT, n0 = ns * 16 * NT;
     const typename KView<TA>::type A{reinterpret_cast<const TA*>(a.v), a.V, a.B};
     const ViewCContig Bv{a.W, a.H, a.H, a.V};
-    // Epilogue map: the 32 x 16 strip has 512 outputs: one per thread (FAST) or two consecutive columns per thread.
-    using SO = StripOut<MT, NT, CP, 256 * SPLIT>;
+    // Epilogue map: the 32 x 16 strip has 512 outputs = 2 consecutive columns for each of the 256 threads.
+    using SO = StripOut<MT, NT, CP>;
     static_assert(SO::NP == 1, "one output (pair) per thread");
     const int row = m0 + SO::row(0), j0 = n0 + CP * SO::cg(0);
     const int i_c = min(row, a.B - 1), j_c = min(j0, a.H - 1), j_c1 = min(j0 + 1, a.H - 1);
@@ -115,27 +112,27 @@ __global__ __launch_bounds__(FAST ? 512 : 256) void k_hidden(HiddenArgs a)
     // consumed in `pre`, while those transfers are in flight.
     //   a.epiDma (FAST kernels, aligned operands): every vector-memory instruction of a wavefront costs the kernel's start
     //       about as much as a 1 KiB operand transfer, so instead of 1 + 2*C loads per thread THREE LDS-DMA transfers per
-    //       wavefront fetch the bias tile (64 B), the 16-column tile of U (C x 64 B) and the y rows of its 4 strip rows
-    //       (4 x 4C B, contiguous) into a 2 KiB scratch of its own, read back with ds_read behind vm_wait.  (Loads into
+    //       wavefront fetch the bias tile (64 B), the 16-column tile of U (C x 64 B) and the y rows of its 8 strip rows
+    //       (8 x 4C B, contiguous) into a 3 KiB scratch of its own, read back with ds_read behind vm_wait.  (Loads into
     //       registers that the compiler does not track are not an option here: it may copy their destination registers --
     //       the hooks sit in the panel loop -- before the data has arrived.)
     //   otherwise: ordinary loads, the compiler places the waits.
     const bool with_dma = FAST && a.epiDma;
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
-    char* cls_lds = lds + a.ldsCls + wv * 2048;   // [0, 1024) U tile, [1024, 1536) y rows, [1536, 1600) bias tile
+    char* cls_lds = lds + a.ldsCls + wv * 3072;   // one 1 KiB slot per transfer (a transfer WRITES all of it): U tile, y rows, bias tile
     float d_g[2] = {0.f, 0.f}, y_g[CM], u_g[CM][2];
     auto pre0 = [&]() {
         if (with_dma) {   // by ALL lanes of the wavefront (a lane masked off would leave its chunk out)
             // bias: lanes 0..3 = the four 16-byte chunks of d[n0 .. n0+15];
             // U tile: lanes 0..4C-1: chunk (class = lane/4, columns n0 + 4*(lane%4) ..);
-            // y rows: lanes 0..C-1: chunk `lane` of the 4*C floats of rows m0 + 4*wv ..;
+            // y rows: lanes 0..2C-1: chunk `lane` of the 8*C floats of rows m0 + 8*wv ..;
             // everything else, and rows / columns beyond the operands, read as zeros through the descriptors' range check
             const rsrc_t rd = make_rsrc(a.d, (unsigned)(a.H * 4));
-            blds16(rd, lane < 4 ? (unsigned)((n0 + 4 * lane) * 4) : kOOB, cls_lds + 1536 - 0);
+            blds16(rd, lane < 4 ? (unsigned)((n0 + 4 * lane) * 4) : kOOB, cls_lds + 2048);
             if (with_cls) {
                 const rsrc_t ru = make_rsrc(a.U, (unsigned)(a.C * a.H * 4)), ry = make_rsrc(a.y, (unsigned)(a.B * a.C * 4));
                 blds16(ru, lane < 4 * a.C ? (unsigned)(((lane >> 2) * a.H + n0 + 4 * (lane & 3)) * 4) : kOOB, cls_lds);
-                blds16(ry, lane < a.C ? (unsigned)(((m0 + 4 * wv) * a.C + 4 * lane) * 4) : kOOB, cls_lds + 1024);
+                blds16(ry, lane < 2 * a.C ? (unsigned)(((m0 + 8 * wv) * a.C + 4 * lane) * 4) : kOOB, cls_lds + 1024);
             }
         } else {
             d_g[0] = a.d[j_c];
@@ -155,7 +152,7 @@ __global__ __launch_bounds__(FAST ? 512 : 256) void k_hidden(HiddenArgs a)
         const bool on = c < a.C;
         const float yv = on ? y : 0.f;
         cls[0] = __builtin_fmaf(yv, on ? u0 : 0.f, cls[0]);
-        if constexpr (CP == 2) cls[1] = __builtin_fmaf(yv, on ? u1 : 0.f, cls[1]);
+        cls[1] = __builtin_fmaf(yv, on ? u1 : 0.f, cls[1]);
     };
     auto pre = [&](int n_younger) {
         if (MODE == 0 && (a.s || a.s8)) {
@@ -163,13 +160,8 @@ __global__ __launch_bounds__(FAST ? 512 : 256) void k_hidden(HiddenArgs a)
             uint32_t prow = a.row0 + (uint32_t)row;
             asm volatile("" : "+v"(prow));   // the draw depends on this statement's position: it cannot be hoisted above the transfers
             const f32x4 u4 = uniform4(a.seed, a.offset, prow, (uint32_t)(j0 >> 2));
-            if constexpr (CP == 1) {
-                const int e = j0 & 3;
-                uu[0] = e == 0 ? u4[0] : e == 1 ? u4[1] : e == 2 ? u4[2] : u4[3];
-            } else {
-                uu[0] = (j0 & 2) ? u4[2] : u4[0];
-                uu[1] = (j0 & 2) ? u4[3] : u4[1];
-            }
+            uu[0] = (j0 & 2) ? u4[2] : u4[0];   // this thread's pair is the lower or the upper half of the block
+            uu[1] = (j0 & 2) ? u4[3] : u4[1];
             asm volatile("" : "+v"(uu[0]), "+v"(uu[1]));   // ... nor sunk behind the wait below
         }
         if (!with_dma) {
@@ -180,35 +172,34 @@ __global__ __launch_bounds__(FAST ? 512 : 256) void k_hidden(HiddenArgs a)
             }
             return;
         }
-        if constexpr (CP == 1) {   // (with_dma implies the FAST kernel: one column per thread)
-            vm_wait(n_younger);   // this wavefront's transfers of pre0 (and everything older) have landed: visible to its ds_reads
-            // Row r of the wavefront (= lane/16) has its C floats at 1024 + 4*C*r; column (lane%16) of class c sits at
-            // 64*c + 4*(lane%16), its bias at 1536 + 4*(lane%16).  Reads beyond class C-1 return whatever the scratch holds:
-            // masked in `chain`.
-            const uint32_t ya = lds_off(cls_lds) + 1024u + (uint32_t)(4 * a.C * (lane >> 4)), ua = lds_off(cls_lds) + 4u * (lane & 15);
-            uint32_t d_l, y_l[CM], u_l[CM];
-            asm volatile("ds_read_b32 %0, %1 offset:1536" : "=v"(d_l) : "v"(ua) : "memory");
-            if (with_cls) {
+        vm_wait(n_younger);   // this wavefront's transfers of pre0 (and everything older) have landed: visible to its ds_reads
+        // Row r of the wavefront (= lane/8) has its C floats at 1024 + 4*C*r; column pair (lane%8) of class c sits at
+        // 64*c + 8*(lane%8), its bias pair at 2048 + 8*(lane%8).  Reads beyond class C-1 return whatever the scratch holds:
+        // masked in `chain`.
+        const uint32_t ya = lds_off(cls_lds) + 1024u + (uint32_t)(4 * a.C * (lane >> 3)), ua = lds_off(cls_lds) + 8u * (lane & 7);
+        u32x2 d_l, u_l[CM];
+        uint32_t y_l[CM];
+        asm volatile("ds_read_b64 %0, %1 offset:2048" : "=v"(d_l) : "v"(ua) : "memory");
+        if (with_cls) {
 #pragma unroll
-                for (int c = 0; c < CM; ++c) {
-                    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(y_l[c]) : "v"(ya), "n"(4 * c) : "memory");
-                    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(u_l[c]) : "v"(ua), "n"(64 * c) : "memory");
-                }
+            for (int c = 0; c < CM; ++c) {
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(y_l[c]) : "v"(ya), "n"(4 * c) : "memory");
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(u_l[c]) : "v"(ua), "n"(64 * c) : "memory");
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            asm volatile("" : "+v"(d_l));
-            dv[0] = __uint_as_float(d_l);
-            if (with_cls) {
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("" : "+v"(d_l));
+        dv[0] = __uint_as_float(d_l[0]); dv[1] = __uint_as_float(d_l[1]);
+        if (with_cls) {
 #pragma unroll
-                for (int c = 0; c < CM; ++c) {
-                    asm volatile("" : "+v"(y_l[c]), "+v"(u_l[c]));
-                    chain(c, __uint_as_float(y_l[c]), __uint_as_float(u_l[c]), 0.f);
-                }
+            for (int c = 0; c < CM; ++c) {
+                asm volatile("" : "+v"(y_l[c]), "+v"(u_l[c]));
+                chain(c, __uint_as_float(y_l[c]), __uint_as_float(u_l[c][0]), __uint_as_float(u_l[c][1]));
             }
         }
     };
     QBM_STAMP(11);
-    const auto o = strip_mma<MT, NT, FAST, FAST, CP, SPLIT>(A, Bv, m0, n0, a.V, lds, a.KP, pre0, pre);
+    const auto o = strip_mma<MT, NT, FAST, FAST, CP>(A, Bv, m0, n0, a.V, lds, a.KP, pre0, pre);
     if (o.valid(0) && row < a.B && j0 < a.H) {
         const float sv[2] = {o.sum[0].x, o.sum[0].y};
         float pv[2], hv[2];
@@ -929,20 +920,20 @@ int launch_hidden_t(const qbm_rbm_params* P, const void* v, const float* y, int 
                       small2g((long)B * P->V, ASZ) && small2g((long)P->V * P->H, 4);
     const int nM = (B + 16 * MT - 1) / (16 * MT), nN = (P->H + 16 * NT - 1) / (16 * NT);
     size_t lds = strip_lds_bytes<MT, NT, ASZ>(a.KP);
-    // epilogue operands by LDS-DMA: one transfer instruction must hold the U tile (4*C chunks of 16 B), another the 4 y rows
-    // of a wavefront (C chunks); whole, 16-byte aligned chunks only
+    // epilogue operands by LDS-DMA: one transfer instruction must hold the U tile (4*C chunks of 16 B), another the 8 y rows
+    // of a wavefront (2*C chunks); whole, 16-byte aligned chunks only
     const bool cls = mode == 0 && y;
     a.epiDma = fast && NT == 1 && MT == 2 && aligned16(P->d) &&
                (!cls || (4 * P->C <= 64 && ((long)B * P->C) % 4 == 0 && aligned16(y) && aligned16(P->U) &&
                          small2g((long)B * P->C, 4) && small2g((long)P->C * P->H, 4)));
     if (a.epiDma) {
         a.ldsCls = (int)lds;
-        lds += 8 * 2048;   // 2 KiB per wavefront of the 512-thread workgroup
+        lds += 4 * 3072;   // three 1 KiB transfer slots per wavefront
     }
 #define QBM_LAUNCH(F, MODE, CM)                                                                  \
     {                                                                                            \
         if (int rc = set_lds(k_hidden<TA, F, MODE, CM>, lds)) return rc;                         \
-        hipLaunchKernelGGL((k_hidden<TA, F, MODE, CM>), dim3(nM * nN), dim3(F ? 512 : 256), lds, st, a); \
+        hipLaunchKernelGGL((k_hidden<TA, F, MODE, CM>), dim3(nM * nN), dim3(256), lds, st, a);   \
     }
     if (mode != 0 || !y) {  // no class term: the class-count bucket is irrelevant
         if (mode == 0) { if (fast) QBM_LAUNCH(true, 0, 2) else QBM_LAUNCH(false, 0, 2) }

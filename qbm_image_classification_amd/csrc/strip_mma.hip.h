@@ -298,21 +298,19 @@ __host__ __device__ constexpr int strip_max_panel()
 
 // What one thread holds after the four partial strips are combined.  CPT = consecutive columns per output (4, or 2
 // for strips so small that 4 columns per thread would leave half of the workgroup without an epilogue):
-// NP = ceil(256*MT*NT / (CPT*THREADS)) outputs; output p of thread t is row (t + THREADS*p) / (16*NT/CPT), column group
-// (t + THREADS*p) % (16*NT/CPT) of the strip (columns CPT*cg .. CPT*cg + CPT - 1), sum[p] = ((q0+q1)+q2)+q3
-// (CPT == 2: in .x, .y; CPT == 1: in .x).
-template <int MT, int NT, int CPT = 4, int THREADS = 256>
+// NP = ceil(MT*NT*64 / (64*CPT)) outputs; output p of thread t is row (t + 256p) / (16*NT/CPT), column group
+// (t + 256p) % (16*NT/CPT) of the strip (columns CPT*cg .. CPT*cg + CPT - 1), sum[p] = ((q0+q1)+q2)+q3
+// (CPT == 2: in .x, .y).
+template <int MT, int NT, int CPT = 4>
 struct StripOut {
-    static_assert(CPT == 4 || CPT == 2 || CPT == 1, "4, 2 or 1 columns per thread");
+    static_assert(CPT == 4 || CPT == 2, "4 or 2 columns per thread");
     static constexpr int kCG = 16 * NT / CPT;                       // column groups per strip row
-    static constexpr int NP = (16 * MT * kCG + THREADS - 1) / THREADS;
+    static constexpr int NP = (16 * MT * kCG + 255) / 256;
     float4 sum[NP];
-    // THREADS = 256: the thread's index inside its group of four wavefronts (a 512-thread workgroup of k_grad is two groups,
-    // each running a contraction of its own); THREADS = 512: the epilogue of a SPLIT = 2 contraction, shared by all 8 waves
-    __device__ __forceinline__ static int t(int p) { return ((int)threadIdx.x & (THREADS - 1)) + THREADS * p; }
-    __device__ __forceinline__ static bool valid(int p) { return t(p) < 16 * MT * kCG; }
-    __device__ __forceinline__ static int row(int p) { return t(p) / kCG; }
-    __device__ __forceinline__ static int cg(int p) { return t(p) % kCG; }
+    // (threadIdx.x & 255: a 512-thread workgroup is two groups of 256 threads, each running a contraction of its own)
+    __device__ __forceinline__ static bool valid(int p) { return ((int)threadIdx.x & 255) + 256 * p < 16 * MT * kCG; }
+    __device__ __forceinline__ static int row(int p) { return (((int)threadIdx.x & 255) + 256 * p) / kCG; }
+    __device__ __forceinline__ static int cg(int p) { return (((int)threadIdx.x & 255) + 256 * p) % kCG; }
 };
 
 // hook of strip_mma that does nothing
@@ -350,22 +348,12 @@ __device__ __forceinline__ void vm_wait(int n)
 //   pre(n)  right after those of the second quad (n = vector-memory instructions this wave has issued since pre0):
 //           the place for arithmetic, and for consuming pre0's loads behind vm_wait(n).
 // On the register-staged path both run first (n = 0).
-//
-// SPLIT = 2 (512-thread workgroup, LDS-DMA path only): wavefronts 0..3 take the first MT/2 row tiles of the strip,
-// wavefronts 4..7 the others; the two wavefronts of a K quarter stage their own A tiles and every other piece of the B
-// tiles, which both read (a workgroup barrier per quad publishes the transfers of the partner).  Two wavefronts per SIMD:
-// while one is parked on a transfer, an LDS read or the barrier, the other issues MFMAs, and the VALU work around the
-// contraction (Philox, sigmoid) runs at the two-wave issue rate.  Same sums: a tile is still contracted quarter by quarter
-// by one wavefront each.  The epilogue map covers all 512 threads (StripOut<.., 512>).
-template <int MT, int NT, bool FAST_A, bool FAST_B, int CPT = 4, int SPLIT = 1, class AView, class BView, class Pre0 = NoPre,
-          class Pre = NoPre>
-__device__ __forceinline__ StripOut<MT, NT, CPT, 256 * SPLIT> strip_mma(const AView& A, const BView& Bv, int m0, int n0, int K,
-                                                                        char* __restrict__ lds, int KP, Pre0&& pre0 = NoPre{},
-                                                                        Pre&& pre = NoPre{}, int stamp0 = 0)
+template <int MT, int NT, bool FAST_A, bool FAST_B, int CPT = 4, class AView, class BView, class Pre0 = NoPre, class Pre = NoPre>
+__device__ __forceinline__ StripOut<MT, NT, CPT> strip_mma(const AView& A, const BView& Bv, int m0, int n0, int K,
+                                                           char* __restrict__ lds, int KP, Pre0&& pre0 = NoPre{},
+                                                           Pre&& pre = NoPre{}, int stamp0 = 0)
 {
     (void)stamp0;   // first stamp slot of this call (diagnostic builds only)
-    static_assert(SPLIT == 1 || (SPLIT == 2 && FAST_A && FAST_B && MT % 2 == 0), "SPLIT = 2: LDS-DMA path, even MT");
-    constexpr int MTW = MT / SPLIT;   // row tiles of one wavefront
     using TA = typename AView::elem;
     const int qbm_diag = QBM_DIAG_MODE;   // 0 in the product: the diagnostic branches fold away
     constexpr bool A8 = sizeof(TA) == 1;
@@ -374,9 +362,7 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 256 * SPLIT> strip_mma(const AV
     static_assert(sizeof(typename BView::elem) == 4, "the B operand is fp32");
     const int tid = threadIdx.x & 255;   // the thread's index inside its group of four wavefronts
     const int lane = tid & 63;
-    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave id (mod 4) == K quarter (wave-uniform, SGPR)
-    const int grp = SPLIT == 2 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;   // SPLIT = 2: which half of the row tiles
-    const int ti0 = grp * MTW;           // first row tile of this wavefront
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave id == K quarter (wave-uniform, SGPR)
     const int Kq = quarter_len(K);
     const int kq0 = q * Kq;
     const int kend = min(K, kq0 + Kq);
@@ -388,9 +374,9 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 256 * SPLIT> strip_mma(const AV
     constexpr bool A_TILES = A8 && !A_K4;
     const int a_tile = A_TILES ? 16 : 16 * KP * ASZ, b_tile = 16 * KP * 4;
 
-    f32x4 acc[MTW][NT];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < MTW; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     QBM_STAMP(stamp0 + 0);
@@ -409,12 +395,12 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 256 * SPLIT> strip_mma(const AV
     // MFMAs.  The reads of piece p+1 are issued before the MFMAs of piece p behind counted lgkmcnt waits (LDS
     // returns in order; a wait after the first <= 15 reads of p+1 covers everything older).
     constexpr int kReadsA = A8 ? 4 : 2, kReadsB = 2;
-    constexpr int MT1 = (15 - kReadsB * NT) / kReadsA < MTW ? (15 - kReadsB * NT) / kReadsA : MTW;  // tiles in chunk 1
+    constexpr int MT1 = (15 - kReadsB * NT) / kReadsA < MT ? (15 - kReadsB * NT) / kReadsA : MT;  // tiles in chunk 1
     constexpr int kChunk1 = kReadsB * NT + kReadsA * MT1;   // <= 15 = the largest lgkmcnt
     constexpr int kPieceA = A8 ? (A_TILES ? 256 * MT : 256) : 1024;   // bytes from piece to piece at one tile's base address
     struct Frag {
-        u32x2 a2[MTW][2];     // fp32: k-steps (0,1) and (2,3)
-        uint32_t a1[MTW][4];  // u8: one zero-extended byte per k-step
+        u32x2 a2[MT][2];     // fp32: k-steps (0,1) and (2,3)
+        uint32_t a1[MT][4];  // u8: one zero-extended byte per k-step
         u32x2 b[NT][2];
     };
     auto readA = [&](auto PC, uint32_t ad, int i, Frag& f) {
@@ -453,7 +439,7 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 256 * SPLIT> strip_mma(const AV
             asm volatile("" : "+v"(f.b[t][1]));
         }
 #pragma unroll
-        for (int i = 0; i < MTW; ++i) {
+        for (int i = 0; i < MT; ++i) {
             if constexpr (A8) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(f.a1[i][s]));
@@ -464,9 +450,9 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 256 * SPLIT> strip_mma(const AV
         }
     };
     auto mma = [&](const Frag& f) {
-        float av[MTW][4];
+        float av[MT][4];
 #pragma unroll
-        for (int i = 0; i < MTW; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
 #ifdef QBM_DIAG_NOCVT
@@ -478,12 +464,12 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 256 * SPLIT> strip_mma(const AV
             }
         if constexpr (A8) {   // the widenings as one burst in front of the MFMAs (no wait states between them)
 #pragma unroll
-            for (int i = 0; i < MTW; ++i) asm volatile("" : "+v"(av[i][0]), "+v"(av[i][1]), "+v"(av[i][2]), "+v"(av[i][3]));
+            for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(av[i][0]), "+v"(av[i][1]), "+v"(av[i][2]), "+v"(av[i][3]));
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int i = 0; i < MTW; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
                     acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][s], __uint_as_float(f.b[t][s >> 1][s & 1]), acc[i][t], 0, 0, 0);
@@ -493,9 +479,9 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 256 * SPLIT> strip_mma(const AV
     auto run_quad_n = [&](auto NPC, int qd) {
         constexpr int NP = decltype(NPC)::value;
         using std::integral_constant;
-        uint32_t adA[MTW], adB[NT];
+        uint32_t adA[MT], adB[NT];
 #pragma unroll
-        for (int i = 0; i < MTW; ++i) adA[i] = lds_off(imgA) + (uint32_t)(fragA + (ti0 + i) * a_tile + qd * 4 * kPieceA);
+        for (int i = 0; i < MT; ++i) adA[i] = lds_off(imgA) + (uint32_t)(fragA + i * a_tile + qd * 4 * kPieceA);
 #pragma unroll
         for (int t = 0; t < NT; ++t) adB[t] = lds_off(imgB) + (uint32_t)(fragB + t * b_tile + qd * 4096);
         auto reads1 = [&](auto PC, Frag& f) {   // chunk 1: at most 15 reads
@@ -506,7 +492,7 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 256 * SPLIT> strip_mma(const AV
         };
         auto reads2 = [&](auto PC, Frag& f) {
 #pragma unroll
-            for (int i = MT1; i < MTW; ++i) readA(PC, adA[i], i, f);
+            for (int i = MT1; i < MT; ++i) readA(PC, adA[i], i, f);
         };
         // one pipeline stage: issue the reads of piece NXT into `fn` (if the quad has it), then the MFMAs of the piece in `fc`
         auto stage = [&](auto NXT, Frag& fn, Frag& fc) {
@@ -546,64 +532,7 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 256 * SPLIT> strip_mma(const AV
     for (int kb = kq0; kb < kq0 + Kq; kb += KP) {
         const int klen = max(0, min(kend - kb, KP));
         const int pieces = (klen + 15) >> 4;   // 16 k per piece (klen is a multiple of 16 on the FAST path)
-        if constexpr (SPLIT == 2) {
-            static_assert(!(A8 && !A_K4), "SPLIT = 2 is for K-contiguous A operands (k_hidden, k_visible)");
-            // ---- LDS-DMA by the two wavefronts of the quarter: own A tiles, every other B piece; two quads ahead.
-            // Every wavefront of the workgroup runs the SAME number of barriers per panel (quads_all, from the full
-            // quarter length), whatever its own quarter holds.
-            const rsrc_t ra = A.rsrc(), rb = Bv.rsrc();
-            DmaLane la[MTW], lb[NT];
-#pragma unroll
-            for (int i = 0; i < MTW; ++i) la[i] = A.lane0(m0 + 16 * (ti0 + i), kb, lane);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) lb[t] = Bv.lane0(n0 + 16 * t, kb, lane);
-            const int quads = (pieces + 3) >> 2;
-            const int quads_all = ((min(kq0 + Kq - kb, KP) + 15) / 16 + 3) >> 2;
-            auto quad_pieces = [&](int qd) { return max(0, min(4, pieces - 4 * qd)); };
-            auto own_b = [&](int qd) { const int np = quad_pieces(qd); return grp == 0 ? (np + 1) >> 1 : np >> 1; };   // pieces 4qd + grp, + 2, ..
-            auto quad_dmas = [&](int qd) { return qd < quads ? (A8 ? MTW : MTW * quad_pieces(qd)) + NT * own_b(qd) : 0; };
-            auto issue_quad = [&](int qd) {
-                const int np = quad_pieces(qd);
-                if constexpr (A8) {
-#pragma unroll
-                    for (int i = 0; i < MTW; ++i) {
-                        blds16(ra, la[i].k < kend ? la[i].voff : kOOB, imgA + (ti0 + i) * a_tile + qd * 1024);
-                        la[i].voff += la[i].step;
-                        la[i].k += la[i].kstep;
-                    }
-                }
-                for (int pc = 4 * qd; pc < 4 * qd + np; ++pc) {
-                    if constexpr (!A8) {
-#pragma unroll
-                        for (int i = 0; i < MTW; ++i) {
-                            blds16(ra, la[i].voff, imgA + (ti0 + i) * a_tile + pc * 1024);
-                            la[i].voff += la[i].step;
-                        }
-                    }
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        if ((pc & 1) == grp) blds16(rb, lb[t].voff, imgB + t * b_tile + pc * 1024);
-                        lb[t].voff += lb[t].step;
-                    }
-                }
-            };
-            if (quads > 0) issue_quad(0);
-            if (kb == kq0) pre0();
-            if (quads > 1) issue_quad(1);
-            QBM_STAMP(stamp0 + 1);
-            if (kb == kq0) pre(quad_dmas(1));
-            for (int qd = 0; qd < quads_all; ++qd) {
-                if (qd + 2 < quads) issue_quad(qd + 2);
-                vm_wait(quad_dmas(qd + 1) + quad_dmas(qd + 2));   // this wavefront's transfers of quad qd have landed ...
-                __builtin_amdgcn_s_barrier();                     // ... and so have its partner's
-                if (qd == 0) QBM_STAMP(stamp0 + 2);
-                if (qd < quads) {
-                    if (quad_pieces(qd) == 4) run_quad_n(std::integral_constant<int, 4>{}, qd);
-                    else run_quad(qd, quad_pieces(qd));
-                }
-            }
-            if (kb + KP < kq0 + Kq) __builtin_amdgcn_s_barrier();   // another panel follows: it reuses the images both waves have read
-        } else if constexpr (FAST_A && FAST_B) {
+        if constexpr (FAST_A && FAST_B) {
             // ---- LDS-DMA, two quads ahead of the MFMAs: the transfers of quads q+1, q+2 are in flight while quad q
             // is contracted.  The compiler does not order a ds_read behind a pending LDS-DMA, so each quad sits
             // behind an explicit counted vmcnt wait.
@@ -733,18 +662,17 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 256 * SPLIT> strip_mma(const AV
     // [16*MT][RS], RS = 16*NT + 4 (the +4 keeps lanes l and l+16, four rows apart, on different banks)
     constexpr int RS = 16 * NT + 4;
     float* red = reinterpret_cast<float*>(img);
-    if constexpr (SPLIT == 2) __builtin_amdgcn_s_barrier();   // the partner may still be reading the head of the staging region
 #pragma unroll
-    for (int i = 0; i < MTW; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[(16 * (ti0 + i) + (lane >> 4) * 4 + r) * RS + 16 * t + (lane & 15)] = acc[i][t][r];
+            for (int r = 0; r < 4; ++r) red[(16 * i + (lane >> 4) * 4 + r) * RS + 16 * t + (lane & 15)] = acc[i][t][r];
     __syncthreads();
 
-    StripOut<MT, NT, CPT, 256 * SPLIT> o;
+    StripOut<MT, NT, CPT> o;
 #pragma unroll
-    for (int p = 0; p < StripOut<MT, NT, CPT, 256 * SPLIT>::NP; ++p) {
+    for (int p = 0; p < StripOut<MT, NT, CPT>::NP; ++p) {
         o.sum[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (o.valid(p)) {
             const char* base = lds + (size_t)(o.row(p) * RS + CPT * o.cg(p)) * 4;
@@ -757,19 +685,13 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 256 * SPLIT> strip_mma(const AV
                 o.sum[p].y = ((p0.y + p1.y) + p2.y) + p3.y;
                 o.sum[p].z = ((p0.z + p1.z) + p2.z) + p3.z;
                 o.sum[p].w = ((p0.w + p1.w) + p2.w) + p3.w;
-            } else if constexpr (CPT == 2) {
+            } else {
                 const float2 p0 = *reinterpret_cast<const float2*>(base);
                 const float2 p1 = *reinterpret_cast<const float2*>(base + wave_bytes);
                 const float2 p2 = *reinterpret_cast<const float2*>(base + 2 * (size_t)wave_bytes);
                 const float2 p3 = *reinterpret_cast<const float2*>(base + 3 * (size_t)wave_bytes);
                 o.sum[p].x = ((p0.x + p1.x) + p2.x) + p3.x;
                 o.sum[p].y = ((p0.y + p1.y) + p2.y) + p3.y;
-            } else {
-                const float p0 = *reinterpret_cast<const float*>(base);
-                const float p1 = *reinterpret_cast<const float*>(base + wave_bytes);
-                const float p2 = *reinterpret_cast<const float*>(base + 2 * (size_t)wave_bytes);
-                const float p3 = *reinterpret_cast<const float*>(base + 3 * (size_t)wave_bytes);
-                o.sum[p].x = ((p0 + p1) + p2) + p3;
             }
         }
     }
