@@ -110,30 +110,37 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
     // (classes c >= C enter it as 0 * 0, which is exact), the Philox draw -- is taken out of the tail of the kernel AND out
     // of its head: the operands are requested in `pre0`, i.e. behind the first operand transfers of the contraction, and
     // consumed in `pre`, while those transfers are in flight.
-    //   a.epiDma (FAST kernels, aligned operands): every vector-memory instruction of a wavefront costs the kernel's start
-    //       about as much as a 1 KiB operand transfer, so instead of 1 + 2*C loads per thread THREE LDS-DMA transfers per
-    //       wavefront fetch the bias tile (64 B), the 16-column tile of U (C x 64 B) and the y rows of its 8 strip rows
-    //       (8 x 4C B, contiguous) into a 3 KiB scratch of its own, read back with ds_read behind vm_wait.  (Loads into
-    //       registers that the compiler does not track are not an option here: it may copy their destination registers --
-    //       the hooks sit in the panel loop -- before the data has arrived.)
+    //   a.epiDma (FAST kernels, aligned operands, C <= 10): a vector-memory instruction of a wavefront costs the kernel's
+    //       start ~250 cycles whatever it moves, so instead of 1 + 2*C loads per thread ONE LDS-DMA transfer per wavefront
+    //       (global_load_lds_dwordx4: a 64-bit address per lane) fetches the 16-column tile of U (C x 64 B), the y rows of
+    //       its 8 strip rows (8 x 4C B, contiguous) and the bias tile (64 B) -- 6C + 4 <= 64 chunks of 16 bytes -- into a
+    //       1 KiB scratch of its own, read back with ds_read behind vm_wait.  (Loads into registers that the compiler does
+    //       not track are not an option here: it may copy their destination registers -- the hooks sit in the panel loop --
+    //       before the data has arrived.)
     //   otherwise: ordinary loads, the compiler places the waits.
     const bool with_dma = FAST && a.epiDma;
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
-    char* cls_lds = lds + a.ldsCls + wv * 3072;   // one 1 KiB slot per transfer (a transfer WRITES all of it): U tile, y rows, bias tile
+    char* cls_lds = lds + a.ldsCls + wv * 1024;   // chunk of lane L at 16 L: [0, 64C) U tile, [64C, 96C) y rows, [96C, 96C + 64) bias tile
     float d_g[2] = {0.f, 0.f}, y_g[CM], u_g[CM][2];
     auto pre0 = [&]() {
-        if (with_dma) {   // by ALL lanes of the wavefront (a lane masked off would leave its chunk out)
-            // bias: lanes 0..3 = the four 16-byte chunks of d[n0 .. n0+15];
-            // U tile: lanes 0..4C-1: chunk (class = lane/4, columns n0 + 4*(lane%4) ..);
-            // y rows: lanes 0..2C-1: chunk `lane` of the 8*C floats of rows m0 + 8*wv ..;
-            // everything else, and rows / columns beyond the operands, read as zeros through the descriptors' range check
-            const rsrc_t rd = make_rsrc(a.d, (unsigned)(a.H * 4));
-            blds16(rd, lane < 4 ? (unsigned)((n0 + 4 * lane) * 4) : kOOB, cls_lds + 2048);
-            if (with_cls) {
-                const rsrc_t ru = make_rsrc(a.U, (unsigned)(a.C * a.H * 4)), ry = make_rsrc(a.y, (unsigned)(a.B * a.C * 4));
-                blds16(ru, lane < 4 * a.C ? (unsigned)(((lane >> 2) * a.H + n0 + 4 * (lane & 3)) * 4) : kOOB, cls_lds);
-                blds16(ry, lane < 2 * a.C ? (unsigned)(((m0 + 8 * wv) * a.C + 4 * lane) * 4) : kOOB, cls_lds + 1024);
+        if (with_dma) {   // decided per wavefront (never per lane: a lane masked off by an outer condition would leave its chunk out)
+            // lane L < 4C: U chunk (class L/4, columns n0 + 4*(L%4) ..); 4C <= L < 6C: chunk L - 4C of the 8*C floats of rows
+            // m0 + 8*wv .. (no class term: none of these); the 4 lanes behind them: the chunks of d[n0 .. n0+15].
+            // No range check on this path: lanes whose chunk lies beyond the operand are masked off (their LDS slot keeps
+            // its old bytes; only threads of rows >= B / columns >= H would read it).
+            const int nU = with_cls ? 4 * a.C : 0, nY = with_cls ? 2 * a.C : 0;
+            const float* src = nullptr;
+            if (lane < nU) {
+                const int col = n0 + 4 * (lane & 3);
+                if (col < a.H) src = a.U + (long)(lane >> 2) * a.H + col;
+            } else if (lane < nU + nY) {
+                const long f = (long)(m0 + 8 * wv) * a.C + 4 * (lane - nU);
+                if (f < (long)a.B * a.C) src = a.y + f;
+            } else if (lane < nU + nY + 4) {
+                const int col = n0 + 4 * (lane - nU - nY);
+                if (col < a.H) src = a.d + col;
             }
+            if (src) __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)cls_lds, 16, 0, 0);
         } else {
             d_g[0] = a.d[j_c];
             d_g[1] = a.d[j_c1];
@@ -173,13 +180,15 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
             return;
         }
         vm_wait(n_younger);   // this wavefront's transfers of pre0 (and everything older) have landed: visible to its ds_reads
-        // Row r of the wavefront (= lane/8) has its C floats at 1024 + 4*C*r; column pair (lane%8) of class c sits at
-        // 64*c + 8*(lane%8), its bias pair at 2048 + 8*(lane%8).  Reads beyond class C-1 return whatever the scratch holds:
-        // masked in `chain`.
-        const uint32_t ya = lds_off(cls_lds) + 1024u + (uint32_t)(4 * a.C * (lane >> 3)), ua = lds_off(cls_lds) + 8u * (lane & 7);
+        // Row r of the wavefront (= lane/8) has its C floats at 64C + 4*C*r; column pair (lane%8) of class c sits at
+        // 64*c + 8*(lane%8), its bias pair at 96C + 8*(lane%8) (no class term: at 8*(lane%8)).  Reads beyond class C-1
+        // return whatever the scratch holds: masked in `chain`.
+        const uint32_t ua = lds_off(cls_lds) + 8u * (lane & 7);
+        const uint32_t ya = lds_off(cls_lds) + (uint32_t)(64 * a.C + 4 * a.C * (lane >> 3));
+        const uint32_t da = ua + (with_cls ? (uint32_t)(96 * a.C) : 0u);
         u32x2 d_l, u_l[CM];
         uint32_t y_l[CM];
-        asm volatile("ds_read_b64 %0, %1 offset:2048" : "=v"(d_l) : "v"(ua) : "memory");
+        asm volatile("ds_read_b64 %0, %1" : "=v"(d_l) : "v"(da) : "memory");
         if (with_cls) {
 #pragma unroll
             for (int c = 0; c < CM; ++c) {
@@ -920,15 +929,14 @@ int launch_hidden_t(const qbm_rbm_params* P, const void* v, const float* y, int 
                       small2g((long)B * P->V, ASZ) && small2g((long)P->V * P->H, 4);
     const int nM = (B + 16 * MT - 1) / (16 * MT), nN = (P->H + 16 * NT - 1) / (16 * NT);
     size_t lds = strip_lds_bytes<MT, NT, ASZ>(a.KP);
-    // epilogue operands by LDS-DMA: one transfer instruction must hold the U tile (4*C chunks of 16 B), another the 8 y rows
-    // of a wavefront (2*C chunks); whole, 16-byte aligned chunks only
+    // epilogue operands by LDS-DMA: ONE transfer instruction holds the U tile (4*C chunks of 16 B), the 8 y rows of a
+    // wavefront (2*C chunks) and the bias tile (4 chunks); whole, 16-byte aligned chunks only
     const bool cls = mode == 0 && y;
     a.epiDma = fast && NT == 1 && MT == 2 && aligned16(P->d) &&
-               (!cls || (4 * P->C <= 64 && ((long)B * P->C) % 4 == 0 && aligned16(y) && aligned16(P->U) &&
-                         small2g((long)B * P->C, 4) && small2g((long)P->C * P->H, 4)));
+               (!cls || (6 * P->C + 4 <= 64 && ((long)B * P->C) % 4 == 0 && aligned16(y) && aligned16(P->U)));
     if (a.epiDma) {
         a.ldsCls = (int)lds;
-        lds += 4 * 3072;   // three 1 KiB transfer slots per wavefront
+        lds += 4 * 1024;   // one 1 KiB transfer slot per wavefront
     }
 #define QBM_LAUNCH(F, MODE, CM)                                                                  \
     {                                                                                            \
