@@ -117,7 +117,9 @@ __device__ __forceinline__ float wave_butterfly_sum(float p)
     return p;
 }
 
-// [Q] length of one K quarter: roundup16(ceil(K / 4)) -- a whole number of 16-k staging pieces
-__host__ __device__ __forceinline__ int quarter_len(int K) { return (((K + 3) / 4) + 15) / 16 * 16; }
+// [Q] length of one of the NQ chains a contraction of length K is cut into: roundup16(ceil(K / NQ)) -- a whole number of
+// 16-k staging pieces.  NQ = 4 ("quarters": the gradient, contracted over the batch) or 8 (the conditionals).
+__host__ __device__ __forceinline__ int chain_len(int K, int nq) { return (((K + nq - 1) / nq) + 15) / 16 * 16; }
+__host__ __device__ __forceinline__ int quarter_len(int K) { return chain_len(K, 4); }
 
 }  // namespace qbm

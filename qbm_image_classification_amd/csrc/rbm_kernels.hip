@@ -83,11 +83,13 @@ struct HiddenArgs {
     int ldsCls;    // byte offset of the per-wavefront scratch of those transfers (2 KiB each) in the dynamic LDS
 };
 
+// 8 wavefronts (512 threads): wavefront q contracts chain q of the 8 the K = V terms are cut into ([Q] with NQ = 8), two
+// wavefronts per SIMD; one output column per thread in the epilogue.
+constexpr int H_NQ = 8;
 template <class TA, bool FAST, int MODE, int CM>
-__global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
+__global__ __launch_bounds__(64 * H_NQ) void k_hidden(HiddenArgs a)
 {
-    constexpr int MT = H_MT, NT = H_NT;
-    constexpr int CP = 2;   // epilogue columns per thread
+    constexpr int MT = H_MT, NT = H_NT, NQ = H_NQ;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     QBM_STAMP(10);
     // every kernel argument in ONE round trip to the (cold) scalar cache: the compiler otherwise fetches them where they
@@ -100,41 +102,41 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
     const int m0 = ms * 16 * MT, n0 = ns * 16 * NT;
     const typename KView<TA>::type A{reinterpret_cast<const TA*>(a.v), a.V, a.B};
     const ViewCContig Bv{a.W, a.H, a.H, a.V};
-    // Epilogue map: the 32 x 16 strip has 512 outputs = 2 consecutive columns for each of the 256 threads.
-    using SO = StripOut<MT, NT, CP>;
-    static_assert(SO::NP == 1, "one output (pair) per thread");
-    const int row = m0 + SO::row(0), j0 = n0 + CP * SO::cg(0);
-    const int i_c = min(row, a.B - 1), j_c = min(j0, a.H - 1), j_c1 = min(j0 + 1, a.H - 1);
+    // Epilogue map: the 32 x 16 strip has 512 outputs: one per thread.
+    using SO = StripOut<MT, NT, 1, 64 * NQ>;
+    static_assert(SO::NP == 1, "one output per thread");
+    const int row = m0 + SO::row(0), j0 = n0 + SO::cg(0);
+    const int i_c = min(row, a.B - 1), j_c = min(j0, a.H - 1);
     const bool with_cls = MODE == 0 && a.y != nullptr;
     // Everything of the epilogue that does not depend on the contraction -- bias and class-term operands, the class chain
     // (classes c >= C enter it as 0 * 0, which is exact), the Philox draw -- is taken out of the tail of the kernel AND out
     // of its head: the operands are requested in `pre0`, i.e. behind the first operand transfers of the contraction, and
     // consumed in `pre`, while those transfers are in flight.
-    //   a.epiDma (FAST kernels, aligned operands, C <= 10): a vector-memory instruction of a wavefront costs the kernel's
+    //   a.epiDma (FAST kernels, aligned operands, C <= 12): a vector-memory instruction of a wavefront costs the kernel's
     //       start ~250 cycles whatever it moves, so instead of 1 + 2*C loads per thread ONE LDS-DMA transfer per wavefront
     //       (global_load_lds_dwordx4: a 64-bit address per lane) fetches the 16-column tile of U (C x 64 B), the y rows of
-    //       its 8 strip rows (8 x 4C B, contiguous) and the bias tile (64 B) -- 6C + 4 <= 64 chunks of 16 bytes -- into a
+    //       its 4 strip rows (4 x 4C B, contiguous) and the bias tile (64 B) -- 5C + 4 <= 64 chunks of 16 bytes -- into a
     //       1 KiB scratch of its own, read back with ds_read behind vm_wait.  (Loads into registers that the compiler does
     //       not track are not an option here: it may copy their destination registers -- the hooks sit in the panel loop --
     //       before the data has arrived.)
     //   otherwise: ordinary loads, the compiler places the waits.
     const bool with_dma = FAST && a.epiDma;
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
-    char* cls_lds = lds + a.ldsCls + wv * 1024;   // chunk of lane L at 16 L: [0, 64C) U tile, [64C, 96C) y rows, [96C, 96C + 64) bias tile
-    float d_g[2] = {0.f, 0.f}, y_g[CM], u_g[CM][2];
+    char* cls_lds = lds + a.ldsCls + wv * 1024;   // chunk of lane L at 16 L: [0, 64C) U tile, [64C, 80C) y rows, [80C, 80C + 64) bias tile
+    float d_g = 0.f, y_g[CM], u_g[CM];
     auto pre0 = [&]() {
         if (with_dma) {   // decided per wavefront (never per lane: a lane masked off by an outer condition would leave its chunk out)
-            // lane L < 4C: U chunk (class L/4, columns n0 + 4*(L%4) ..); 4C <= L < 6C: chunk L - 4C of the 8*C floats of rows
-            // m0 + 8*wv .. (no class term: none of these); the 4 lanes behind them: the chunks of d[n0 .. n0+15].
+            // lane L < 4C: U chunk (class L/4, columns n0 + 4*(L%4) ..); 4C <= L < 5C: chunk L - 4C of the 4*C floats of rows
+            // m0 + 4*wv .. (no class term: none of these); the 4 lanes behind them: the chunks of d[n0 .. n0+15].
             // No range check on this path: lanes whose chunk lies beyond the operand are masked off (their LDS slot keeps
             // its old bytes; only threads of rows >= B / columns >= H would read it).
-            const int nU = with_cls ? 4 * a.C : 0, nY = with_cls ? 2 * a.C : 0;
+            const int nU = with_cls ? 4 * a.C : 0, nY = with_cls ? a.C : 0;
             const float* src = nullptr;
             if (lane < nU) {
                 const int col = n0 + 4 * (lane & 3);
                 if (col < a.H) src = a.U + (long)(lane >> 2) * a.H + col;
             } else if (lane < nU + nY) {
-                const long f = (long)(m0 + 8 * wv) * a.C + 4 * (lane - nU);
+                const long f = (long)(m0 + 4 * wv) * a.C + 4 * (lane - nU);
                 if (f < (long)a.B * a.C) src = a.y + f;
             } else if (lane < nU + nY + 4) {
                 const int col = n0 + 4 * (lane - nU - nY);
@@ -142,99 +144,81 @@ __global__ __launch_bounds__(256) void k_hidden(HiddenArgs a)
             }
             if (src) __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)cls_lds, 16, 0, 0);
         } else {
-            d_g[0] = a.d[j_c];
-            d_g[1] = a.d[j_c1];
+            d_g = a.d[j_c];
             if (with_cls) {
 #pragma unroll
                 for (int c = 0; c < CM; ++c) {
                     y_g[c] = a.y[(long)i_c * a.C + min(c, a.C - 1)];
-                    u_g[c][0] = a.U[(long)min(c, a.C - 1) * a.H + j_c];
-                    u_g[c][1] = a.U[(long)min(c, a.C - 1) * a.H + j_c1];
+                    u_g[c] = a.U[(long)min(c, a.C - 1) * a.H + j_c];
                 }
             }
         }
     };
-    float dv[2] = {0.f, 0.f}, cls[2] = {0.f, 0.f}, uu[2] = {0.f, 0.f};
-    auto chain = [&](int c, float y, float u0, float u1) {   // class c of the class term (classes >= C enter as 0 * 0)
+    float dv = 0.f, cls = 0.f, uu = 0.f;
+    auto chain = [&](int c, float y, float u) {   // class c of the class term (classes >= C enter as 0 * 0)
         const bool on = c < a.C;
-        const float yv = on ? y : 0.f;
-        cls[0] = __builtin_fmaf(yv, on ? u0 : 0.f, cls[0]);
-        cls[1] = __builtin_fmaf(yv, on ? u1 : 0.f, cls[1]);
+        cls = __builtin_fmaf(on ? y : 0.f, on ? u : 0.f, cls);
     };
     auto pre = [&](int n_younger) {
         if (MODE == 0 && (a.s || a.s8)) {
-            // one Philox block serves columns 4*(j0>>2) .. +3
+            // one Philox block serves columns 4*(j0>>2) .. +3: this thread takes word j0 & 3
             uint32_t prow = a.row0 + (uint32_t)row;
             asm volatile("" : "+v"(prow));   // the draw depends on this statement's position: it cannot be hoisted above the transfers
             const f32x4 u4 = uniform4(a.seed, a.offset, prow, (uint32_t)(j0 >> 2));
-            uu[0] = (j0 & 2) ? u4[2] : u4[0];   // this thread's pair is the lower or the upper half of the block
-            uu[1] = (j0 & 2) ? u4[3] : u4[1];
-            asm volatile("" : "+v"(uu[0]), "+v"(uu[1]));   // ... nor sunk behind the wait below
+            const int e = j0 & 3;
+            uu = e == 0 ? u4[0] : e == 1 ? u4[1] : e == 2 ? u4[2] : u4[3];
+            asm volatile("" : "+v"(uu));   // ... nor sunk behind the wait below
         }
         if (!with_dma) {
-            dv[0] = d_g[0]; dv[1] = d_g[1];
+            dv = d_g;
             if (with_cls) {
 #pragma unroll
-                for (int c = 0; c < CM; ++c) chain(c, y_g[c], u_g[c][0], u_g[c][1]);
+                for (int c = 0; c < CM; ++c) chain(c, y_g[c], u_g[c]);
             }
             return;
         }
-        vm_wait(n_younger);   // this wavefront's transfers of pre0 (and everything older) have landed: visible to its ds_reads
-        // Row r of the wavefront (= lane/8) has its C floats at 64C + 4*C*r; column pair (lane%8) of class c sits at
-        // 64*c + 8*(lane%8), its bias pair at 96C + 8*(lane%8) (no class term: at 8*(lane%8)).  Reads beyond class C-1
+        vm_wait(n_younger);   // this wavefront's transfer of pre0 (and everything older) has landed: visible to its ds_reads
+        // Row r of the wavefront (= lane/16) has its C floats at 64C + 4*C*r; column (lane%16) of class c sits at
+        // 64*c + 4*(lane%16), its bias at 80C + 4*(lane%16) (no class term: at 4*(lane%16)).  Reads beyond class C-1
         // return whatever the scratch holds: masked in `chain`.
-        const uint32_t ua = lds_off(cls_lds) + 8u * (lane & 7);
-        const uint32_t ya = lds_off(cls_lds) + (uint32_t)(64 * a.C + 4 * a.C * (lane >> 3));
-        const uint32_t da = ua + (with_cls ? (uint32_t)(96 * a.C) : 0u);
-        u32x2 d_l, u_l[CM];
-        uint32_t y_l[CM];
-        asm volatile("ds_read_b64 %0, %1" : "=v"(d_l) : "v"(da) : "memory");
+        const uint32_t ua = lds_off(cls_lds) + 4u * (lane & 15);
+        const uint32_t ya = lds_off(cls_lds) + (uint32_t)(64 * a.C + 4 * a.C * (lane >> 4));
+        const uint32_t da = ua + (with_cls ? (uint32_t)(80 * a.C) : 0u);
+        uint32_t d_l, y_l[CM], u_l[CM];
+        asm volatile("ds_read_b32 %0, %1" : "=v"(d_l) : "v"(da) : "memory");
         if (with_cls) {
 #pragma unroll
             for (int c = 0; c < CM; ++c) {
                 asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(y_l[c]) : "v"(ya), "n"(4 * c) : "memory");
-                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(u_l[c]) : "v"(ua), "n"(64 * c) : "memory");
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(u_l[c]) : "v"(ua), "n"(64 * c) : "memory");
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         asm volatile("" : "+v"(d_l));
-        dv[0] = __uint_as_float(d_l[0]); dv[1] = __uint_as_float(d_l[1]);
+        dv = __uint_as_float(d_l);
         if (with_cls) {
 #pragma unroll
             for (int c = 0; c < CM; ++c) {
                 asm volatile("" : "+v"(y_l[c]), "+v"(u_l[c]));
-                chain(c, __uint_as_float(y_l[c]), __uint_as_float(u_l[c][0]), __uint_as_float(u_l[c][1]));
+                chain(c, __uint_as_float(y_l[c]), __uint_as_float(u_l[c]));
             }
         }
     };
     QBM_STAMP(11);
-    const auto o = strip_mma<MT, NT, FAST, FAST, CP>(A, Bv, m0, n0, a.V, lds, a.KP, pre0, pre);
+    const auto o = strip_mma<MT, NT, FAST, FAST, 1, NQ>(A, Bv, m0, n0, a.V, lds, a.KP, pre0, pre);
     if (o.valid(0) && row < a.B && j0 < a.H) {
-        const float sv[2] = {o.sum[0].x, o.sum[0].y};
-        float pv[2], hv[2];
-#pragma unroll
-        for (int e = 0; e < CP; ++e) {
-            float x = sv[e] + dv[e];
-            if (MODE == 0) {
-                if (a.y) x = x + cls[e];
-                pv[e] = det_sigmoid(x);
-                hv[e] = (pv[e] > uu[e]) ? 1.f : 0.f;
-            } else {
-                pv[e] = x; hv[e] = 0.f;
-            }
+        float x = o.sum[0].x + dv, pv, hv = 0.f;
+        if (MODE == 0) {
+            if (a.y) x = x + cls;
+            pv = det_sigmoid(x);
+            hv = (pv > uu) ? 1.f : 0.f;
+        } else {
+            pv = x;
         }
         const long off = (long)row * a.H + j0;
-        if (CP == 2 && a.vecO && j0 + 1 < a.H) {
-            if (a.p) *reinterpret_cast<float2*>(a.p + off) = make_float2(pv[0], pv[1]);
-            if (MODE == 0 && a.s) *reinterpret_cast<float2*>(a.s + off) = make_float2(hv[0], hv[1]);
-            if (MODE == 0 && a.s8) *reinterpret_cast<uint16_t*>(a.s8 + off) = (uint16_t)((uint32_t)hv[0] | ((uint32_t)hv[1] << 8));
-        } else {
-            for (int e = 0; e < CP && j0 + e < a.H; ++e) {
-                if (a.p) a.p[off + e] = pv[e];
-                if (MODE == 0 && a.s) a.s[off + e] = hv[e];
-                if (MODE == 0 && a.s8) a.s8[off + e] = (uint8_t)hv[e];
-            }
-        }
+        if (a.p) a.p[off] = pv;
+        if (MODE == 0 && a.s) a.s[off] = hv;
+        if (MODE == 0 && a.s8) a.s8[off] = (uint8_t)hv;
     }
     QBM_STAMP(12);
 }
@@ -343,16 +327,20 @@ struct VisibleArgs {
     int n_aux;  // aux workgroups come first in the grid
 };
 
+// 8 wavefronts (512 threads) per strip workgroup: wavefront q contracts chain q of the 8 the K = H terms are cut into
+// ([Q] with NQ = 8); two visible units per thread in the epilogue.
+constexpr int V_NQ = 8;
 template <class TA, bool FAST, int CM>
-__global__ __launch_bounds__(256) void k_visible(VisibleArgs a)
+__global__ __launch_bounds__(64 * V_NQ) void k_visible(VisibleArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    if ((int)blockIdx.x < a.n_aux) {  // aux workgroup (dealt first): class conditional of one row
+    if ((int)blockIdx.x < a.n_aux) {  // aux workgroup (dealt first): class conditional of one row, by its first 4 wavefronts
+        if (threadIdx.x >= 256) return;   // (a wavefront that has ended does not take part in the workgroup's barriers)
         class_row<TA, CM>(a.h, a.U, a.cb, a.py, a.ys, (int)blockIdx.x, a.H, a.C, a.seed, a.offset_y, a.row0,
                           reinterpret_cast<float*>(lds));
         return;
     }
-    constexpr int MT = V_MT, NT = V_NT;
+    constexpr int MT = V_MT, NT = V_NT, NQ = V_NQ;
     QBM_STAMP(10);
     asm volatile("" ::"s"(a.h), "s"(a.W), "s"(a.b), "s"(a.p), "s"(a.s), "s"(a.s8), "s"(a.B), "s"(a.V), "s"(a.H), "s"(a.KP),
                  "s"(a.seed), "s"(a.offset), "s"(a.row0));   // all arguments in one scalar-cache round trip (see k_hidden)
@@ -362,58 +350,50 @@ __global__ __launch_bounds__(256) void k_visible(VisibleArgs a)
     const int m0 = ms * 16 * MT, n0 = ns * 16 * NT;
     const typename KView<TA>::type A{reinterpret_cast<const TA*>(a.h), a.H, a.B};
     const ViewKContig Bv{a.W, a.H, a.V};
+    // Epilogue map: the 64 x 16 strip has 1024 outputs = 2 consecutive visible units for each of the 512 threads.
     // The bias loads are issued behind the first operand transfers (`pre0`) and consumed in the epilogue; the Philox draw
     // runs in `pre`, while the transfers are in flight.
-    using SO = StripOut<MT, NT>;
-    float bv[SO::NP][4];
-    f32x4 uu[SO::NP];
+    using SO = StripOut<MT, NT, 2, 64 * NQ>;
+    static_assert(SO::NP == 1, "one output pair per thread");
+    const int i = m0 + SO::row(0), k0 = n0 + 2 * SO::cg(0);
+    const bool pair = a.vecO && k0 + 1 < a.V;
+    float bv[2] = {0.f, 0.f}, uu[2] = {0.f, 0.f};
     auto pre0 = [&]() {
-#pragma unroll
-        for (int op = 0; op < SO::NP; ++op) {
-            const int k0 = n0 + 4 * SO::cg(op);
-            if (a.vecO && k0 + 3 < a.V) {
-                const float4 t = *reinterpret_cast<const float4*>(a.b + k0);
-                bv[op][0] = t.x; bv[op][1] = t.y; bv[op][2] = t.z; bv[op][3] = t.w;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) bv[op][e] = a.b[min(k0 + e, a.V - 1)];
-            }
+        if (pair) {
+            const float2 t = *reinterpret_cast<const float2*>(a.b + k0);
+            bv[0] = t.x; bv[1] = t.y;
+        } else {
+            bv[0] = a.b[min(k0, a.V - 1)];
+            bv[1] = a.b[min(k0 + 1, a.V - 1)];
         }
     };
     auto pre = [&](int) {
-#pragma unroll
-        for (int op = 0; op < SO::NP; ++op) {
-            const int k0 = n0 + 4 * SO::cg(op);
-            uu[op] = f32x4{0.f, 0.f, 0.f, 0.f};
-            uint32_t prow = a.row0 + (uint32_t)(m0 + SO::row(op));
-            asm volatile("" : "+v"(prow));     // the draw depends on this statement's position: not hoisted above the transfers,
-            if (a.s || a.s8) uu[op] = uniform4(a.seed, a.offset, prow, (uint32_t)(k0 >> 2));
-            asm volatile("" : "+v"(uu[op]));   // not sunk into the epilogue
+        uint32_t prow = a.row0 + (uint32_t)i;
+        asm volatile("" : "+v"(prow));     // the draw depends on this statement's position: not hoisted above the transfers,
+        if (a.s || a.s8) {
+            const f32x4 u4 = uniform4(a.seed, a.offset, prow, (uint32_t)(k0 >> 2));
+            uu[0] = (k0 & 2) ? u4[2] : u4[0];   // this thread's pair is the lower or the upper half of the block
+            uu[1] = (k0 & 2) ? u4[3] : u4[1];
         }
+        asm volatile("" : "+v"(uu[0]), "+v"(uu[1]));   // not sunk into the epilogue
     };
     QBM_STAMP(11);
-    const auto o = strip_mma<MT, NT, FAST, FAST>(A, Bv, m0, n0, a.H, lds, a.KP, pre0, pre);
+    const auto o = strip_mma<MT, NT, FAST, FAST, 2, NQ>(A, Bv, m0, n0, a.H, lds, a.KP, pre0, pre);
+    if (o.valid(0) && i < a.B && k0 < a.V) {
+        const float sv[2] = {o.sum[0].x, o.sum[0].y};
+        float pv[2], vv[2];
 #pragma unroll
-    for (int op = 0; op < o.NP; ++op) {
-        if (!o.valid(op)) continue;
-        const int i = m0 + o.row(op), k0 = n0 + 4 * o.cg(op);
-        if (i >= a.B || k0 >= a.V) continue;
-        const bool vec = a.vecO && k0 + 3 < a.V;
-        const float sv[4] = {o.sum[op].x, o.sum[op].y, o.sum[op].z, o.sum[op].w};
-        float pv[4], vv[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            pv[e] = det_sigmoid(sv[e] + bv[op][e]);
-            vv[e] = (pv[e] > uu[op][e]) ? 1.f : 0.f;
+        for (int e = 0; e < 2; ++e) {
+            pv[e] = det_sigmoid(sv[e] + bv[e]);
+            vv[e] = (pv[e] > uu[e]) ? 1.f : 0.f;
         }
         const long off = (long)i * a.V + k0;
-        if (vec) {
-            if (a.p) *reinterpret_cast<float4*>(a.p + off) = make_float4(pv[0], pv[1], pv[2], pv[3]);
-            if (a.s) *reinterpret_cast<float4*>(a.s + off) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-            if (a.s8)
-                *reinterpret_cast<uint32_t*>(a.s8 + off) = (uint32_t)vv[0] | ((uint32_t)vv[1] << 8) | ((uint32_t)vv[2] << 16) | ((uint32_t)vv[3] << 24);
+        if (pair) {
+            if (a.p) *reinterpret_cast<float2*>(a.p + off) = make_float2(pv[0], pv[1]);
+            if (a.s) *reinterpret_cast<float2*>(a.s + off) = make_float2(vv[0], vv[1]);
+            if (a.s8) *reinterpret_cast<uint16_t*>(a.s8 + off) = (uint16_t)((uint32_t)vv[0] | ((uint32_t)vv[1] << 8));
         } else {
-            for (int e = 0; e < 4 && k0 + e < a.V; ++e) {
+            for (int e = 0; e < 2 && k0 + e < a.V; ++e) {
                 if (a.p) a.p[off + e] = pv[e];
                 if (a.s) a.s[off + e] = vv[e];
                 if (a.s8) a.s8[off + e] = (uint8_t)vv[e];
@@ -914,34 +894,41 @@ int zero_grads(const qbm_rbm_params* P, const qbm_rbm_grads* G, hipStream_t st)
 
 inline bool small2g(long elems, int esz) { return elems * esz < (1L << 31); }
 
+template <int MT, int NT, int ASZ, int NQ>
+int panel_for_nq(int K, int reserve)
+{
+    const int Kq = chain_len(K, NQ);
+    const int KP = (Kq + 63) / 64 * 64;
+    const int mx = strip_max_panel<MT, NT, ASZ, NQ>(reserve);
+    return KP < mx ? KP : mx;
+}
+
 template <class TA>
 int launch_hidden_t(const qbm_rbm_params* P, const void* v, const float* y, int B, float* p, float* s, uint8_t* s8,
                     int mode, uint64_t seed, uint64_t offset, uint32_t row0, hipStream_t st)
 {
-    constexpr int ASZ = (int)sizeof(TA), MT = H_MT, NT = H_NT;
-    HiddenArgs a{v, y, P->W, P->d, P->U, p, s, s8, B, P->V, P->H, P->C, panel_for<MT, NT, ASZ>(P->V), seed, offset, row0,
-                 // column pairs: 8-byte accesses to p / h_f32 / d / U, 2-byte accesses to h_u8
-                 (P->H % 2 == 0) && (!p || aligned8(p)) && (!s || aligned8(s)) && (!s8 || aligned2(s8)) &&
-                     aligned8(P->d) && aligned8(P->U),
-                 false, 0};
+    constexpr int ASZ = (int)sizeof(TA), MT = H_MT, NT = H_NT, NQ = H_NQ;
+    constexpr int kScratch = NQ * 1024;   // one 1 KiB transfer slot per wavefront for the epilogue operands
+    HiddenArgs a{v, y, P->W, P->d, P->U, p, s, s8, B, P->V, P->H, P->C, panel_for_nq<MT, NT, ASZ, NQ>(P->V, kScratch), seed,
+                 offset, row0, false, false, 0};
     // LDS-DMA path: whole 16-k pieces, 16-byte aligned units, descriptors below 2 GiB
     const bool fast = (P->V % 16 == 0) && aligned16(v) && (P->H % 4 == 0) && aligned16(P->W) &&
                       small2g((long)B * P->V, ASZ) && small2g((long)P->V * P->H, 4);
     const int nM = (B + 16 * MT - 1) / (16 * MT), nN = (P->H + 16 * NT - 1) / (16 * NT);
-    size_t lds = strip_lds_bytes<MT, NT, ASZ>(a.KP);
-    // epilogue operands by LDS-DMA: ONE transfer instruction holds the U tile (4*C chunks of 16 B), the 8 y rows of a
-    // wavefront (2*C chunks) and the bias tile (4 chunks); whole, 16-byte aligned chunks only
+    size_t lds = strip_lds_bytes<MT, NT, ASZ, NQ>(a.KP);
+    // epilogue operands by LDS-DMA: ONE transfer instruction holds the U tile (4*C chunks of 16 B), the 4 y rows of a
+    // wavefront (C chunks) and the bias tile (4 chunks); whole, 16-byte aligned chunks only
     const bool cls = mode == 0 && y;
     a.epiDma = fast && NT == 1 && MT == 2 && aligned16(P->d) &&
-               (!cls || (6 * P->C + 4 <= 64 && ((long)B * P->C) % 4 == 0 && aligned16(y) && aligned16(P->U)));
+               (!cls || (5 * P->C + 4 <= 64 && ((long)B * P->C) % 4 == 0 && aligned16(y) && aligned16(P->U)));
     if (a.epiDma) {
         a.ldsCls = (int)lds;
-        lds += 4 * 1024;   // one 1 KiB transfer slot per wavefront
+        lds += kScratch;
     }
-#define QBM_LAUNCH(F, MODE, CM)                                                                  \
-    {                                                                                            \
-        if (int rc = set_lds(k_hidden<TA, F, MODE, CM>, lds)) return rc;                         \
-        hipLaunchKernelGGL((k_hidden<TA, F, MODE, CM>), dim3(nM * nN), dim3(256), lds, st, a);   \
+#define QBM_LAUNCH(F, MODE, CM)                                                                      \
+    {                                                                                                \
+        if (int rc = set_lds(k_hidden<TA, F, MODE, CM>, lds)) return rc;                             \
+        hipLaunchKernelGGL((k_hidden<TA, F, MODE, CM>), dim3(nM * nN), dim3(64 * NQ), lds, st, a);   \
     }
     if (mode != 0 || !y) {  // no class term: the class-count bucket is irrelevant
         if (mode == 0) { if (fast) QBM_LAUNCH(true, 0, 2) else QBM_LAUNCH(false, 0, 2) }
@@ -968,21 +955,22 @@ template <class TA>
 int launch_visible_t(const qbm_rbm_params* P, const void* h, int B, float* p_v, float* v_s, uint8_t* v_s8, float* p_y,
                      float* y1hot, uint64_t seed, uint64_t offset_v, uint64_t offset_y, uint32_t row0, hipStream_t st)
 {
-    constexpr int ASZ = (int)sizeof(TA), MT = V_MT, NT = V_NT;
+    constexpr int ASZ = (int)sizeof(TA), MT = V_MT, NT = V_NT, NQ = V_NQ;
     const bool with_class = p_y || y1hot;
     const int nM = (B + 16 * MT - 1) / (16 * MT), nN = (P->V + 16 * NT - 1) / (16 * NT);
-    VisibleArgs a{h, P->W, P->b, p_v, v_s, v_s8, B, P->V, P->H, panel_for<MT, NT, ASZ>(P->H), seed, offset_v, row0,
-                  (P->V % 4 == 0) && (!p_v || aligned16(p_v)) && (!v_s || aligned16(v_s)) && (!v_s8 || aligned16(v_s8)) &&
-                      aligned16(P->b),
+    VisibleArgs a{h, P->W, P->b, p_v, v_s, v_s8, B, P->V, P->H, panel_for_nq<MT, NT, ASZ, NQ>(P->H, 0), seed, offset_v, row0,
+                  // pairs of visible units: 8-byte accesses to p / v_f32 / b, 2-byte accesses to v_u8
+                  (P->V % 2 == 0) && (!p_v || aligned8(p_v)) && (!v_s || aligned8(v_s)) && (!v_s8 || aligned2(v_s8)) &&
+                      aligned8(P->b),
                   P->U, P->c, p_y, y1hot, P->C, offset_y, with_class ? B : 0};
     const bool fast = (P->H % 16 == 0) && aligned16(h) && aligned16(P->W) && small2g((long)B * P->H, ASZ) &&
                       small2g((long)P->V * P->H, 4);
     const int grid = nM * nN + a.n_aux;
-    const size_t lds = strip_lds_bytes<MT, NT, ASZ>(a.KP);
-#define QBM_LAUNCH(F, CM)                                                                   \
-    {                                                                                       \
-        if (int rc = set_lds(k_visible<TA, F, CM>, lds)) return rc;                         \
-        hipLaunchKernelGGL((k_visible<TA, F, CM>), dim3(grid), dim3(256), lds, st, a);      \
+    const size_t lds = strip_lds_bytes<MT, NT, ASZ, NQ>(a.KP);
+#define QBM_LAUNCH(F, CM)                                                                       \
+    {                                                                                           \
+        if (int rc = set_lds(k_visible<TA, F, CM>, lds)) return rc;                             \
+        hipLaunchKernelGGL((k_visible<TA, F, CM>), dim3(grid), dim3(64 * NQ), lds, st, a);      \
     }
 #define QBM_L(CM) { if (fast) QBM_LAUNCH(true, CM) else QBM_LAUNCH(false, CM) }
     if (!with_class) { QBM_L(2) }

@@ -283,14 +283,15 @@ __host__ __device__ constexpr int strip_wave_bytes(int KP)
     const int red = 16 * MT * (16 * NT + 4) * 4;
     return stage > red ? stage : red;
 }
-template <int MT, int NT, int ASZ>
-__host__ __device__ constexpr int strip_lds_bytes(int KP) { return 4 * strip_wave_bytes<MT, NT, ASZ>(KP); }
+template <int MT, int NT, int ASZ, int NQ = 4>
+__host__ __device__ constexpr int strip_lds_bytes(int KP) { return NQ * strip_wave_bytes<MT, NT, ASZ>(KP); }
 
-// largest panel (multiple of 64) that fits 160 KiB with 4 waves and keeps the DMA count under vm_wait's range
-template <int MT, int NT, int ASZ>
-__host__ __device__ constexpr int strip_max_panel()
+// largest panel (multiple of 64) that fits 160 KiB (less `reserve` bytes) with NQ waves and keeps the DMA count under
+// vm_wait's range
+template <int MT, int NT, int ASZ, int NQ = 4>
+__host__ __device__ constexpr int strip_max_panel(int reserve = 0)
 {
-    int kp = (163840 / 4) / (MT * 16 * ASZ + NT * 16 * 4) / 64 * 64;
+    int kp = ((163840 - reserve) / NQ) / (MT * 16 * ASZ + NT * 16 * 4) / 64 * 64;
     const int per16 = (ASZ == 4 ? MT : 0) + NT;                     // DMA instructions per piece (u8 A: MT per 4 pieces)
     while (kp > 64 && (kp / 16) * per16 + (ASZ == 1 ? MT * (kp / 64) : 0) > 60) kp -= 64;
     return kp;
@@ -298,19 +299,21 @@ __host__ __device__ constexpr int strip_max_panel()
 
 // What one thread holds after the four partial strips are combined.  CPT = consecutive columns per output (4, or 2
 // for strips so small that 4 columns per thread would leave half of the workgroup without an epilogue):
-// NP = ceil(MT*NT*64 / (64*CPT)) outputs; output p of thread t is row (t + 256p) / (16*NT/CPT), column group
-// (t + 256p) % (16*NT/CPT) of the strip (columns CPT*cg .. CPT*cg + CPT - 1), sum[p] = ((q0+q1)+q2)+q3
-// (CPT == 2: in .x, .y).
-template <int MT, int NT, int CPT = 4>
+// NP = ceil(256*MT*NT / (CPT*THREADS)) outputs; output p of thread t is row (t + THREADS*p) / (16*NT/CPT), column group
+// (t + THREADS*p) % (16*NT/CPT) of the strip (columns CPT*cg .. CPT*cg + CPT - 1), sum[p] = (..((q0+q1)+q2)+..)+q_{NQ-1}
+// (CPT == 2: in .x, .y; CPT == 1: in .x).
+template <int MT, int NT, int CPT = 4, int THREADS = 256>
 struct StripOut {
-    static_assert(CPT == 4 || CPT == 2, "4 or 2 columns per thread");
+    static_assert(CPT == 4 || CPT == 2 || CPT == 1, "4, 2 or 1 columns per thread");
     static constexpr int kCG = 16 * NT / CPT;                       // column groups per strip row
-    static constexpr int NP = (16 * MT * kCG + 255) / 256;
+    static constexpr int NP = (16 * MT * kCG + THREADS - 1) / THREADS;
     float4 sum[NP];
-    // (threadIdx.x & 255: a 512-thread workgroup is two groups of 256 threads, each running a contraction of its own)
-    __device__ __forceinline__ static bool valid(int p) { return ((int)threadIdx.x & 255) + 256 * p < 16 * MT * kCG; }
-    __device__ __forceinline__ static int row(int p) { return (((int)threadIdx.x & 255) + 256 * p) / kCG; }
-    __device__ __forceinline__ static int cg(int p) { return (((int)threadIdx.x & 255) + 256 * p) % kCG; }
+    // (threadIdx.x & (THREADS - 1): the thread's index inside the group of THREADS/64 wavefronts that runs the contraction;
+    // a 512-thread workgroup of k_grad is two groups of 256, each with a contraction of its own)
+    __device__ __forceinline__ static int t(int p) { return ((int)threadIdx.x & (THREADS - 1)) + THREADS * p; }
+    __device__ __forceinline__ static bool valid(int p) { return t(p) < 16 * MT * kCG; }
+    __device__ __forceinline__ static int row(int p) { return t(p) / kCG; }
+    __device__ __forceinline__ static int cg(int p) { return t(p) % kCG; }
 };
 
 // hook of strip_mma that does nothing
@@ -348,11 +351,18 @@ __device__ __forceinline__ void vm_wait(int n)
 //   pre(n)  right after those of the second quad (n = vector-memory instructions this wave has issued since pre0):
 //           the place for arithmetic, and for consuming pre0's loads behind vm_wait(n).
 // On the register-staged path both run first (n = 0).
-template <int MT, int NT, bool FAST_A, bool FAST_B, int CPT = 4, class AView, class BView, class Pre0 = NoPre, class Pre = NoPre>
-__device__ __forceinline__ StripOut<MT, NT, CPT> strip_mma(const AView& A, const BView& Bv, int m0, int n0, int K,
-                                                           char* __restrict__ lds, int KP, Pre0&& pre0 = NoPre{},
-                                                           Pre&& pre = NoPre{}, int stamp0 = 0)
+//
+// NQ wavefronts (4 or 8) contract the strip: wavefront q takes chain q of the contraction, chain_len(K, NQ) terms.  NQ = 8 =
+// two wavefronts per SIMD, each with transfers, LDS reads and MFMAs of its own and no synchronisation before the partial
+// strips are combined: while one is parked on a transfer or an LDS read the other issues MFMAs, and the VALU work around
+// the contraction (Philox, sigmoid) issues at the two-wave rate.  (NQ is part of the numerical contract: [Q] in DESIGN.md.)
+template <int MT, int NT, bool FAST_A, bool FAST_B, int CPT = 4, int NQ = 4, class AView, class BView, class Pre0 = NoPre,
+          class Pre = NoPre>
+__device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView& A, const BView& Bv, int m0, int n0, int K,
+                                                                    char* __restrict__ lds, int KP, Pre0&& pre0 = NoPre{},
+                                                                    Pre&& pre = NoPre{}, int stamp0 = 0)
 {
+    static_assert(NQ == 4 || NQ == 8, "4 or 8 chains");
     (void)stamp0;   // first stamp slot of this call (diagnostic builds only)
     using TA = typename AView::elem;
     const int qbm_diag = QBM_DIAG_MODE;   // 0 in the product: the diagnostic branches fold away
@@ -360,10 +370,10 @@ __device__ __forceinline__ StripOut<MT, NT, CPT> strip_mma(const AView& A, const
     constexpr bool A_K4 = AView::kK4, B_K4 = BView::kK4;
     constexpr int ASZ = (int)sizeof(TA);
     static_assert(sizeof(typename BView::elem) == 4, "the B operand is fp32");
-    const int tid = threadIdx.x & 255;   // the thread's index inside its group of four wavefronts
+    const int tid = threadIdx.x & (64 * NQ - 1);   // the thread's index inside its group of NQ wavefronts
     const int lane = tid & 63;
-    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave id == K quarter (wave-uniform, SGPR)
-    const int Kq = quarter_len(K);
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave id == K chain (wave-uniform, SGPR)
+    const int Kq = chain_len(K, NQ);
     const int kq0 = q * Kq;
     const int kend = min(K, kq0 + Kq);
     const int wave_bytes = strip_wave_bytes<MT, NT, ASZ>(KP);
@@ -670,29 +680,35 @@ __device__ __forceinline__ StripOut<MT, NT, CPT> strip_mma(const AView& A, const
             for (int r = 0; r < 4; ++r) red[(16 * i + (lane >> 4) * 4 + r) * RS + 16 * t + (lane & 15)] = acc[i][t][r];
     __syncthreads();
 
-    StripOut<MT, NT, CPT> o;
+    StripOut<MT, NT, CPT, 64 * NQ> o;
 #pragma unroll
-    for (int p = 0; p < StripOut<MT, NT, CPT>::NP; ++p) {
+    for (int p = 0; p < StripOut<MT, NT, CPT, 64 * NQ>::NP; ++p) {
         o.sum[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (o.valid(p)) {
             const char* base = lds + (size_t)(o.row(p) * RS + CPT * o.cg(p)) * 4;
-            if constexpr (CPT == 4) {
-                const float4 p0 = *reinterpret_cast<const float4*>(base);
-                const float4 p1 = *reinterpret_cast<const float4*>(base + wave_bytes);
-                const float4 p2 = *reinterpret_cast<const float4*>(base + 2 * (size_t)wave_bytes);
-                const float4 p3 = *reinterpret_cast<const float4*>(base + 3 * (size_t)wave_bytes);
-                o.sum[p].x = ((p0.x + p1.x) + p2.x) + p3.x;
-                o.sum[p].y = ((p0.y + p1.y) + p2.y) + p3.y;
-                o.sum[p].z = ((p0.z + p1.z) + p2.z) + p3.z;
-                o.sum[p].w = ((p0.w + p1.w) + p2.w) + p3.w;
-            } else {
-                const float2 p0 = *reinterpret_cast<const float2*>(base);
-                const float2 p1 = *reinterpret_cast<const float2*>(base + wave_bytes);
-                const float2 p2 = *reinterpret_cast<const float2*>(base + 2 * (size_t)wave_bytes);
-                const float2 p3 = *reinterpret_cast<const float2*>(base + 3 * (size_t)wave_bytes);
-                o.sum[p].x = ((p0.x + p1.x) + p2.x) + p3.x;
-                o.sum[p].y = ((p0.y + p1.y) + p2.y) + p3.y;
+            float part[NQ][CPT];   // all loads first, then the ordered sums (..((q0 + q1) + q2) + ..) + q_{NQ-1}
+#pragma unroll
+            for (int qq = 0; qq < NQ; ++qq) {
+                if constexpr (CPT == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(base + (size_t)qq * wave_bytes);
+                    part[qq][0] = v.x; part[qq][1] = v.y; part[qq][2] = v.z; part[qq][3] = v.w;
+                } else if constexpr (CPT == 2) {
+                    const float2 v = *reinterpret_cast<const float2*>(base + (size_t)qq * wave_bytes);
+                    part[qq][0] = v.x; part[qq][1] = v.y;
+                } else {
+                    part[qq][0] = *reinterpret_cast<const float*>(base + (size_t)qq * wave_bytes);
+                }
             }
+            float acc[CPT];
+#pragma unroll
+            for (int e = 0; e < CPT; ++e) {
+                acc[e] = part[0][e];
+#pragma unroll
+                for (int qq = 1; qq < NQ; ++qq) acc[e] = acc[e] + part[qq][e];
+            }
+            o.sum[p].x = acc[0];
+            if constexpr (CPT >= 2) o.sum[p].y = acc[1];
+            if constexpr (CPT == 4) { o.sum[p].z = acc[2]; o.sum[p].w = acc[3]; }
         }
     }
     QBM_STAMP(stamp0 + 4);

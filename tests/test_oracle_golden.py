@@ -46,25 +46,31 @@ def test_det_math_accuracy(oracle):
     assert np.isinf(oracle.math("softplus", np.array([100.0]))[0])
 
 
-def test_qgemm_is_quartered_fma_chain(oracle):
+@pytest.mark.parametrize("nq", [4, 8])
+def test_qgemm_is_split_fma_chain(oracle, nq):
+    """[Q]: nq contiguous chains of roundup16(ceil(K/nq)) terms, each an ascending fmaf chain, summed in chain order
+    (8 chains: the conditionals; 4: the gradient blocks)."""
     rs = np.random.RandomState(0)
-    for (M, N, K) in [(3, 5, 16), (2, 4, 9), (4, 3, 784), (1, 2, 1), (2, 2, 5), (2, 3, 100)]:
+    for (M, N, K) in [(3, 5, 16), (2, 4, 9), (4, 3, 784), (1, 2, 1), (2, 2, 5), (2, 3, 100), (2, 2, 512)]:
         A = rs.standard_normal((M, K)).astype(np.float32)
         B = rs.standard_normal((K, N)).astype(np.float32)
-        got = oracle.qgemm(A, B)
-        Kq = ((K + 3) // 4 + 15) // 16 * 16
+        got = oracle.qgemm(A, B, nq)
+        Kq = ((K + nq - 1) // nq + 15) // 16 * 16
         want = np.zeros((M, N), np.float32)
         for m in range(M):
             for n in range(N):
                 parts = []
-                for q in range(4):
+                for q in range(nq):
                     acc = np.float32(0)
                     for k in range(q * Kq, min(K, (q + 1) * Kq)):
                         # exact fma in float64: a*b is exact (48 bits), the sum is rounded once to
                         # 53 bits and again to 24 -- double rounding can differ only on ties
                         acc = np.float32(np.float64(A[m, k]) * np.float64(B[k, n]) + np.float64(acc))
                     parts.append(acc)
-                want[m, n] = np.float32(np.float32(np.float32(parts[0] + parts[1]) + parts[2]) + parts[3])
+                t = parts[0]
+                for q in range(1, nq):
+                    t = np.float32(t + parts[q])
+                want[m, n] = t
         assert np.max(np.abs(got - want)) <= 1e-6 * max(1.0, np.abs(want).max())
         assert np.allclose(got, A.astype(np.float64) @ B.astype(np.float64), rtol=0, atol=1e-4)
 

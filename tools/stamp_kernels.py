@@ -70,8 +70,8 @@ def main():
     Wsc = W.clone()
     p = lambda x: C.c_void_p(x.data_ptr())
     kernels = {
-        "k_hidden": (lambda: lib.qbm_rbm_sample_hidden_ex(C.byref(P), p(v0), 1, p(y0), B, p(ph0), None, p(h), 42, 0, 0, None), 256 * 4),
-        "k_visible": (lambda: lib.qbm_rbm_sample_visible_class_ex(C.byref(P), p(h), 1, B, None, None, p(vk), None, p(yk), 42, 1, 2, 0, None), (196 + 256) * 4),
+        "k_hidden": (lambda: lib.qbm_rbm_sample_hidden_ex(C.byref(P), p(v0), 1, p(y0), B, p(ph0), None, p(h), 42, 0, 0, None), 256 * 8),
+        "k_visible": (lambda: lib.qbm_rbm_sample_visible_class_ex(C.byref(P), p(h), 1, B, None, None, p(vk), None, p(yk), 42, 1, 2, 0, None), (196 + 256) * 8),
         "k_grad": (lambda: lib.qbm_rbm_two_phase_grad(V, H, NC, B, p(v0), 1, p(y0), p(ph0), p(vk), 1, p(yk), p(phk), C.byref(G), p(Wsc), None,
                                                      0.05, 1.0, float(B), 0.0, None), 238 * 8),
     }
