@@ -486,17 +486,9 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
     };
     // the NP pieces of quad `qd`, straight-line (no branch inside: a merge point would cost register copies, and
     // copies are VALU work the MFMAs pay for)
-    // `later` >= 0: LDS-DMA path -- this wave's transfer instructions issued BEHIND those of this quad; the reads of piece p
-    // then sit behind a wait that leaves exactly the transfers of pieces p+1.. and those `later` ones in flight (a quad's
-    // instructions are issued piece by piece, u8 k4 A tiles -- one instruction per quad -- first), so the first MFMA of a
-    // quad needs its first piece only, not the whole quad.  later < 0: everything has landed already.
-    constexpr int kPerPiece = NT + ((A8 && A_K4) ? 0 : (A8 ? 1 : MT));   // transfer instructions per piece
-    auto run_quad_n = [&](auto NPC, int qd, int later) {
+    auto run_quad_n = [&](auto NPC, int qd) {
         constexpr int NP = decltype(NPC)::value;
         using std::integral_constant;
-        auto landed = [&](int piece) {   // wait until piece `piece` of this quad has landed
-            if (later >= 0) vm_wait(later + (NP - 1 - piece) * kPerPiece);
-        };
         uint32_t adA[MT], adB[NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) adA[i] = lds_off(imgA) + (uint32_t)(fragA + i * a_tile + qd * 4 * kPieceA);
@@ -516,7 +508,6 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
         auto stage = [&](auto NXT, Frag& fn, Frag& fc) {
             constexpr int nxt = decltype(NXT)::value;
             if constexpr (nxt < NP) {
-                landed(nxt);
                 reads1(NXT, fn);
                 asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(kChunk1) : "memory");   // everything older than chunk 1 has landed
                 tie(fc);
@@ -528,7 +519,6 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
             mma(fc);
         };
         Frag f0, f1;
-        landed(0);
         reads1(integral_constant<int, 0>{}, f0);
         reads2(integral_constant<int, 0>{}, f0);
         stage(integral_constant<int, 1>{}, f1, f0);
@@ -536,17 +526,17 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
         if constexpr (NP > 2) stage(integral_constant<int, 3>{}, f1, f0);
         if constexpr (NP > 3) stage(integral_constant<int, 4>{}, f0, f1);
     };
-    auto run_quad = [&](int qd, int np, int later) {   // np = pieces in the quad, 1..4 (wave-uniform)
+    auto run_quad = [&](int qd, int np) {   // np = pieces in the quad, 1..4 (wave-uniform)
         using std::integral_constant;
-        if (np >= 4) run_quad_n(integral_constant<int, 4>{}, qd, later);
-        else if (np == 3) run_quad_n(integral_constant<int, 3>{}, qd, later);
-        else if (np == 2) run_quad_n(integral_constant<int, 2>{}, qd, later);
-        else if (np == 1) run_quad_n(integral_constant<int, 1>{}, qd, later);
+        if (np >= 4) run_quad_n(integral_constant<int, 4>{}, qd);
+        else if (np == 3) run_quad_n(integral_constant<int, 3>{}, qd);
+        else if (np == 2) run_quad_n(integral_constant<int, 2>{}, qd);
+        else if (np == 1) run_quad_n(integral_constant<int, 1>{}, qd);
     };
-    auto run = [&](int p0, int p1) {   // whole quads from p0 (a multiple of 4), everything landed
+    auto run = [&](int p0, int p1) {   // whole quads from p0 (a multiple of 4)
         int pc = p0;
-        for (; pc + 4 <= p1; pc += 4) run_quad_n(std::integral_constant<int, 4>{}, pc >> 2, -1);
-        if (pc < p1) run_quad(pc >> 2, p1 - pc, -1);
+        for (; pc + 4 <= p1; pc += 4) run_quad_n(std::integral_constant<int, 4>{}, pc >> 2);
+        if (pc < p1) run_quad(pc >> 2, p1 - pc);
     };
 
     for (int kb = kq0; kb < kq0 + Kq; kb += KP) {
@@ -567,32 +557,21 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
             for (int t = 0; t < NT; ++t) lb[t] = Bv.lane0(n0 + 16 * t, kb, lane);
             const int quads = (pieces + 3) >> 2;
             auto quad_pieces = [&](int qd) { return min(4, pieces - 4 * qd); };
-            auto quad_dmas = [&](int qd) {   // transfer instructions of quad qd
-                if (qd >= quads) return 0;
+            auto quad_dmas = [&](int qd) { return qd < quads ? (A8 ? MT : MT * quad_pieces(qd)) + NT * quad_pieces(qd) : 0; };
+            auto issue_quad = [&](int qd) {
                 const int np = quad_pieces(qd);
-                return ((A8 && A_K4) ? MT : A8 ? np : MT * np) + NT * np;
-            };
-            auto issue_quad = [&](int qd) {   // piece by piece (run_quad_n waits piece by piece); u8 k4 A tiles first
-                const int np = quad_pieces(qd);
-                if constexpr (A8 && A_K4) {
+                if constexpr (A8) {
 #pragma unroll
                     for (int i = 0; i < MT; ++i) {
-                        // one instruction covers the 4 pieces of its tile; lanes past the end of the K chain read zeros
-                        blds16(ra, la[i].k < kend ? la[i].voff : kOOB, imgA + i * a_tile + qd * 1024);
+                        // u8: one instruction covers the 4 pieces (k4 image: of its tile; lin image: a (64/MT)-k slice of
+                        // every tile); lanes past the end of the K quarter read zeros
+                        blds16(ra, la[i].k < kend ? la[i].voff : kOOB, imgA + (A_TILES ? (qd * MT + i) * 1024 : i * a_tile + qd * 1024));
                         la[i].voff += la[i].step;
                         la[i].k += la[i].kstep;
                     }
                 }
                 for (int pc = 4 * qd; pc < 4 * qd + np; ++pc) {
-                    if constexpr (A_TILES) {
-                        // u8 lin image with MT = 4 row tiles: instruction (pc & 3) of the quad = the 16 k of piece pc for all
-                        // of them
-                        static_assert(MT == 4, "LDS-DMA path with a u8 lin A image: 4 row tiles (one instruction per piece)");
-                        const int i = pc & 3;
-                        blds16(ra, la[i].k < kend ? la[i].voff : kOOB, imgA + (qd * MT + i) * 1024);
-                        la[i].voff += la[i].step;
-                        la[i].k += la[i].kstep;
-                    } else if constexpr (!A8) {
+                    if constexpr (!A8) {
 #pragma unroll
                         for (int i = 0; i < MT; ++i) {
                             blds16(ra, la[i].voff, imgA + i * a_tile + pc * 1024);
@@ -611,17 +590,22 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
             if (qbm_diag != 4 && quads > 1) issue_quad(1);
             QBM_STAMP(stamp0 + 1);
             if (kb == kq0) pre(quad_dmas(1));
-            // Quad qd is contracted with the transfers of quads qd+1, qd+2 in flight; inside a quad the pieces are awaited one
-            // by one (run_quad_n), so the count handed down is what has been issued behind quad qd.
-            for (int qd = 0; qd < quads; ++qd) {
-                if (qbm_diag != 4 && qd + 2 < quads) issue_quad(qd + 2);
-                const int later = qbm_diag == 4 ? -1 : quad_dmas(qd + 1) + quad_dmas(qd + 2);
-                if (qbm_diag == 1) vm_wait(0);
-                if (qd == 0) QBM_STAMP(stamp0 + 2);
-                if (qbm_diag != 3) {
-                    if (quad_pieces(qd) == 4) run_quad_n(std::integral_constant<int, 4>{}, qd, later);
-                    else run_quad(qd, quad_pieces(qd), later);
+            // The wait before quad qd leaves exactly the transfers of quads qd+1, qd+2 in flight.  Full quads run in one loop
+            // body (one code path: the accumulators stay in place).
+            const int full = pieces >> 2;
+            int qd = 0;
+            for (; qd < full; ++qd) {
+                if (qbm_diag != 4) {
+                    if (qd + 2 < quads) issue_quad(qd + 2);
+                    vm_wait(qbm_diag == 1 ? 0 : quad_dmas(qd + 1) + quad_dmas(qd + 2));
                 }
+                if (qd == 0) QBM_STAMP(stamp0 + 2);
+                if (qbm_diag != 3) run_quad_n(std::integral_constant<int, 4>{}, qd);
+            }
+            if (qd < quads) {   // tail quad: 1..3 pieces, nothing is in flight behind it
+                if (qbm_diag != 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (qd == 0) QBM_STAMP(stamp0 + 2);
+                if (qbm_diag != 3) run_quad(qd, pieces - 4 * qd);
             }
         } else {
             // ---- at least one operand goes through registers (unaligned / ragged / synthesised)
