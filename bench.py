@@ -86,6 +86,13 @@ def main():
     G = GradSet(V, H, NC, dev)
     lr, factor, sparse = 0.05, 1.0, 0.0
 
+    # steps per captured graph: the requested size, or -- when it does not divide the timed step count -- the largest
+    # divisor of it up to 32, so that a short timed region (the driver runs a few tens of steps) is whole graph replays
+    # rather than a tail of host-bound eager launches
+    if args.graph > 0 and args.steps % args.graph != 0:
+        divs = [d for d in range(2, 33) if args.steps % d == 0]
+        if divs:
+            args.graph = divs[-1]
     # ---- synthetic minibatches, resident in HBM ----------------------------------------------------
     NB = max(8, args.graph if args.graph > 0 else 8)
     row_base = rank * B
