@@ -172,7 +172,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(args.warmup)
+    # warm-up: at least W steps, through the launch path that is timed (whole graph replays when steps are captured)
+    warm_steps = args.warmup if graphs is None else -(-args.warmup // graphs[1]) * graphs[1]
+    run(warm_steps)
     barrier()
     t0 = time.perf_counter()
     run(args.steps)
@@ -222,7 +224,7 @@ def main():
         timed = {k: time_kernel(f) for k, (f, _, _) in kernels.items()}
         dom = max(timed, key=lambda k: timed[k] * kernels[k][2])   # most time per CD-1 step
         # HBM bytes per launch of that kernel from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate
-        # rocprofv3 --pmc passes: tools/gpu_pmc_traffic.sh -> profiles/rNN_pmc_traffic.json); null if absent
+        # rocprofv3 --pmc passes: tools/gpu_profiles.sh -> profiles/rNN_pmc_traffic.json); null if absent
         traffic, traffic_source = None, None
         try:
             import glob
@@ -230,7 +232,7 @@ def main():
             newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]   # latest round's counters
             with open(newest) as f:
                 traffic = json.load(f)["kernels"][dom.split(" ")[0]]["hbm_bytes_per_launch"]
-            # NOT measured in this run: PMC counters need rocprofv3 around the process (tools/gpu_pmc_traffic.sh)
+            # NOT measured in this run: PMC counters need rocprofv3 around the process (tools/gpu_profiles.sh)
             traffic_source = "imported from " + os.path.relpath(newest, ROOT) + " (rocprofv3 --pmc passes of this bench)"
         except (OSError, KeyError, ValueError, IndexError):
             pass
@@ -260,7 +262,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "ClassificationRBM 784v x 512h, C=10, CD-1, batch 256 per GPU (BASELINE.json configs[3] shape; "
                                    "global batch 256*N, RCCL all-reduce of the flat gradient per step when N>1)",
-                       "batch_per_gpu": B, "cd_k": K_CD, "launch": (f"hipGraph x{graphs[1]} steps" if graphs else "eager") + (f" ({graph_note})" if graph_note else ""),
+                       "batch_per_gpu": B, "cd_k": K_CD, "warmup_steps_run": warm_steps, "launch": (f"hipGraph x{graphs[1]} steps" if graphs else "eager") + (f" ({graph_note})" if graph_note else ""),
                        "parallelism": f"dp{world}" + (" (forced data-parallel path)" if args.force_dp and world == 1 else "")},
             "visible_unit_updates_per_sec": round(value * V, 1),
             "roofline": roofline, "cpu_baseline": cpu,

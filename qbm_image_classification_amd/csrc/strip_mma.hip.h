@@ -1,15 +1,15 @@
-// strip_mma.hip.h -- the K-quartered strip contraction every dense product of the path runs on.
+// strip_mma.hip.h -- the K-split strip contraction every dense product of the path runs on.
 //
-// One workgroup = 4 wavefronts = the 4 SIMDs of one CU.  It owns a (16*MT) x (16*NT) strip of the
-// output.  Wave q contracts K-quarter q ([Q] of the numerical contract) with
+// One workgroup = NQ wavefronts (4: one per SIMD of a CU; 8: two per SIMD).  It owns a (16*MT) x (16*NT) strip
+// of the output.  Wave q contracts K chain q ([Q] of the numerical contract) with
 // v_mfma_f32_16x16x4_f32, MT*NT independent accumulators per wave (>= 2 reaches the MFMA issue
-// rate: 32-cycle issue vs 40-cycle dependent latency).  The four partial strips meet in LDS and
-// are added ((q0+q1)+q2)+q3; the caller's epilogue then runs on a row-major thread map
-// (thread -> one row, 4 consecutive columns) so that one Philox4x32 call serves one thread and
-// stores are 16 B wide.
+// rate: 32-cycle issue vs 40-cycle dependent latency).  The NQ partial strips meet in LDS and
+// are added (((q0+q1)+q2)+...); the caller's epilogue then runs on a row-major thread map over ALL threads
+// (StripOut: thread -> one row, CPT consecutive columns) so that one Philox4x32 call serves one thread and
+// stores are up to 16 B wide.
 //
 // What bounds these kernels on MI355X is the L2 -> LDS staging of the operand strips (measured with
-// s_memtime stamps, tools/microbench/stamp_strip.hip), not the MFMA pipe, so the layout minimises
+// s_memtime stamps, tools/stamp_kernels.py), not the MFMA pipe, so the layout minimises
 // staged bytes per workgroup:
 //   * the B operand (W, or the probabilities in the gradient) is fp32;
 //   * the A operand may be uint8: Gibbs states are {0,1}, a byte per unit is exact and 4x smaller;
