@@ -86,9 +86,13 @@ struct HiddenArgs {
 // 8 wavefronts (512 threads): wavefront q contracts chain q of the 8 the K = V terms are cut into ([Q] with NQ = 8), two
 // wavefronts per SIMD; one output column per thread in the epilogue.
 constexpr int H_NQ = 8;
-template <class TA, bool FAST, int MODE, int CM>
+// FASTK: 0 = operands through registers (any shape), 1 = LDS-DMA operands, 2 = LDS-DMA operands and epilogue operands
+// (a compile-time choice: the hooks below must not hold both variants, or the compiler's merge of the two waits for the
+// first operand transfers inside the hook)
+template <class TA, int FASTK, int MODE, int CM>
 __global__ __launch_bounds__(64 * H_NQ) void k_hidden(HiddenArgs a)
 {
+    constexpr bool FAST = FASTK >= 1;
     constexpr int MT = H_MT, NT = H_NT, NQ = H_NQ;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     QBM_STAMP(10);
@@ -120,12 +124,12 @@ __global__ __launch_bounds__(64 * H_NQ) void k_hidden(HiddenArgs a)
     //       not track are not an option here: it may copy their destination registers -- the hooks sit in the panel loop --
     //       before the data has arrived.)
     //   otherwise: ordinary loads, the compiler places the waits.
-    const bool with_dma = FAST && a.epiDma;
+    constexpr bool with_dma = FASTK == 2;
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
     char* cls_lds = lds + a.ldsCls + wv * 1024;   // chunk of lane L at 16 L: [0, 64C) U tile, [64C, 80C) y rows, [80C, 80C + 64) bias tile
     float d_g = 0.f, y_g[CM], u_g[CM];
     auto pre0 = [&]() {
-        if (with_dma) {   // decided per wavefront (never per lane: a lane masked off by an outer condition would leave its chunk out)
+        if constexpr (with_dma) {   // decided per wavefront (never per lane: a lane masked off by an outer condition would leave its chunk out)
             // lane L < 4C: U chunk (class L/4, columns n0 + 4*(L%4) ..); 4C <= L < 5C: chunk L - 4C of the 4*C floats of rows
             // m0 + 4*wv .. (no class term: none of these); the 4 lanes behind them: the chunks of d[n0 .. n0+15].
             // No range check on this path: lanes whose chunk lies beyond the operand are masked off (their LDS slot keeps
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(64 * H_NQ) void k_hidden(HiddenArgs a)
             uu = e == 0 ? u4[0] : e == 1 ? u4[1] : e == 2 ? u4[2] : u4[3];
             asm volatile("" : "+v"(uu));   // ... nor sunk behind the wait below
         }
-        if (!with_dma) {
+        if constexpr (!with_dma) {
             dv = d_g;
             if (with_cls) {
 #pragma unroll
@@ -931,13 +935,14 @@ int launch_hidden_t(const qbm_rbm_params* P, const void* v, const float* y, int 
         hipLaunchKernelGGL((k_hidden<TA, F, MODE, CM>), dim3(nM * nN), dim3(64 * NQ), lds, st, a);   \
     }
     if (mode != 0 || !y) {  // no class term: the class-count bucket is irrelevant
-        if (mode == 0) { if (fast) QBM_LAUNCH(true, 0, 2) else QBM_LAUNCH(false, 0, 2) }
-        else { if (fast) QBM_LAUNCH(true, 1, 2) else QBM_LAUNCH(false, 1, 2) }
+#define QBM_LF(MODE, CM) { if (a.epiDma) QBM_LAUNCH(2, MODE, CM) else if (fast) QBM_LAUNCH(1, MODE, CM) else QBM_LAUNCH(0, MODE, CM) }
+        if (mode == 0) QBM_LF(0, 2) else QBM_LF(1, 2)
     } else {
-#define QBM_L(CM) { if (fast) QBM_LAUNCH(true, 0, CM) else QBM_LAUNCH(false, 0, CM) }
+#define QBM_L(CM) QBM_LF(0, CM)
         QBM_DISPATCH_CM(P->C, QBM_L);
 #undef QBM_L
     }
+#undef QBM_LF
 #undef QBM_LAUNCH
     QBM_CHECK_LAUNCH("k_hidden");
     return QBM_OK;

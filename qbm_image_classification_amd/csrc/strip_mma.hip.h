@@ -544,15 +544,20 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
         if (pc < p1) run_quad(pc >> 2, p1 - pc);
     };
 
-    for (int kb = kq0; kb < kq0 + Kq; kb += KP) {
-        const int klen = max(0, min(kend - kb, KP));
-        const int pieces = (klen + 15) >> 4;   // 16 k per piece (klen is a multiple of 16 on the FAST path)
-        if constexpr (FAST_A && FAST_B) {
-            // ---- LDS-DMA, two quads ahead of the MFMAs: the transfers of quads q+1, q+2 are in flight while quad q
-            // is contracted.  The compiler does not order a ds_read behind a pending LDS-DMA, so each quad sits
-            // behind an explicit counted vmcnt wait.
-            const rsrc_t ra = A.rsrc(), rb = Bv.rsrc();
-            DmaLane la[MT], lb[NT];
+    if constexpr (FAST_A && FAST_B) {
+        // ---- LDS-DMA, one or two quads ahead of the MFMAs: the transfers of the following quads are in flight while quad q
+        // is contracted.  The compiler does not order a ds_read behind a pending LDS-DMA, so each quad sits behind an
+        // explicit counted vmcnt wait.
+        // The first requests of the first panel and the two hooks stand IN FRONT of the panel loop: registers a hook
+        // loads into would otherwise be loop-carried, and the compiler would drain every transfer in flight (vmcnt(0))
+        // where the loop's paths merge -- in front of the first MFMA.
+        const rsrc_t ra = A.rsrc(), rb = Bv.rsrc();
+        DmaLane la[MT], lb[NT];
+        int pieces = 0, quads = 0;
+        auto open_panel = [&](int kb) {   // this lane's walk over panel kb
+            const int klen = max(0, min(kend - kb, KP));
+            pieces = (klen + 15) >> 4;    // 16 k per piece (klen is a multiple of 16 on this path)
+            quads = (pieces + 3) >> 2;
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 if constexpr (A_TILES) la[i] = A.template lane0_tiles<MT>(m0, kb, lane, i);   // instruction i of a quad
@@ -560,46 +565,51 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
             }
 #pragma unroll
             for (int t = 0; t < NT; ++t) lb[t] = Bv.lane0(n0 + 16 * t, kb, lane);
-            const int quads = (pieces + 3) >> 2;
-            auto quad_pieces = [&](int qd) { return min(4, pieces - 4 * qd); };
-            auto quad_dmas = [&](int qd) { return qd < quads ? (A8 ? MT : MT * quad_pieces(qd)) + NT * quad_pieces(qd) : 0; };
-            auto issue_quad = [&](int qd) {
-                const int np = quad_pieces(qd);
-                if constexpr (A8) {
+        };
+        auto quad_pieces = [&](int qd) { return min(4, pieces - 4 * qd); };
+        auto quad_dmas = [&](int qd) { return qd < quads ? (A8 ? MT : MT * quad_pieces(qd)) + NT * quad_pieces(qd) : 0; };
+        auto issue_quad = [&](int qd) {
+            const int np = quad_pieces(qd);
+            if constexpr (A8) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    // u8: one instruction covers the 4 pieces (k4 image: of its tile; lin image: a (64/MT)-k slice of
+                    // every tile); lanes past the end of the K chain read zeros
+                    blds16(ra, la[i].k < kend ? la[i].voff : kOOB, imgA + (A_TILES ? (qd * MT + i) * 1024 : i * a_tile + qd * 1024));
+                    la[i].voff += la[i].step;
+                    la[i].k += la[i].kstep;
+                }
+            }
+            for (int pc = 4 * qd; pc < 4 * qd + np; ++pc) {
+                if constexpr (!A8) {
 #pragma unroll
                     for (int i = 0; i < MT; ++i) {
-                        // u8: one instruction covers the 4 pieces (k4 image: of its tile; lin image: a (64/MT)-k slice of
-                        // every tile); lanes past the end of the K quarter read zeros
-                        blds16(ra, la[i].k < kend ? la[i].voff : kOOB, imgA + (A_TILES ? (qd * MT + i) * 1024 : i * a_tile + qd * 1024));
+                        blds16(ra, la[i].voff, imgA + i * a_tile + pc * 1024);
                         la[i].voff += la[i].step;
-                        la[i].k += la[i].kstep;
                     }
                 }
-                for (int pc = 4 * qd; pc < 4 * qd + np; ++pc) {
-                    if constexpr (!A8) {
 #pragma unroll
-                        for (int i = 0; i < MT; ++i) {
-                            blds16(ra, la[i].voff, imgA + i * a_tile + pc * 1024);
-                            la[i].voff += la[i].step;
-                        }
-                    }
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        blds16(rb, lb[t].voff, imgB + t * b_tile + pc * 1024);
-                        lb[t].voff += lb[t].step;
-                    }
+                for (int t = 0; t < NT; ++t) {
+                    blds16(rb, lb[t].voff, imgB + t * b_tile + pc * 1024);
+                    lb[t].voff += lb[t].step;
                 }
-            };
-            // How far the requests run ahead of the quad being contracted: a chain of one or two quads (the shapes of the
-            // conditionals with 8 chains) asks for its second quad only when the first has landed -- measured 3 % faster on
-            // k_hidden than asking for both up front: the second request no longer competes with the first ones of the other
-            // wavefronts -- longer chains keep two quads in flight.
-            const int ahead = QBM_DMA_AHEAD > 0 ? QBM_DMA_AHEAD : (quads <= 2 ? 1 : 2);
-            if (qbm_diag != 4 && quads > 0) issue_quad(0);
-            if (kb == kq0) pre0();
-            if (ahead >= 2 && qbm_diag != 4 && quads > 1) issue_quad(1);
-            QBM_STAMP(stamp0 + 1);
-            if (kb == kq0) pre(ahead >= 2 ? quad_dmas(1) : 0);
+            }
+        };
+        // How far the requests run ahead of the quad being contracted: 1 = the next quad is requested when the current one
+        // has landed, 2 = two quads in flight.
+        open_panel(kq0);
+        const int ahead = QBM_DMA_AHEAD > 0 ? QBM_DMA_AHEAD : (quads <= 2 ? 1 : 2);
+        if (qbm_diag != 4 && quads > 0) issue_quad(0);
+        pre0();
+        if (ahead >= 2 && qbm_diag != 4 && quads > 1) issue_quad(1);
+        QBM_STAMP(stamp0 + 1);
+        pre(ahead >= 2 ? quad_dmas(1) : 0);
+        for (int kb = kq0; kb < kq0 + Kq; kb += KP) {
+            if (kb != kq0) {
+                open_panel(kb);
+                if (qbm_diag != 4 && quads > 0) issue_quad(0);
+                if (ahead >= 2 && qbm_diag != 4 && quads > 1) issue_quad(1);
+            }
             // The wait before quad qd leaves exactly the transfers of the `ahead` quads behind it in flight.  Full quads
             // run in one loop body (one code path: the accumulators stay in place).
             const int full = pieces >> 2;
@@ -617,9 +627,15 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
                 if (qd == 0) QBM_STAMP(stamp0 + 2);
                 if (qbm_diag != 3) run_quad(qd, pieces - 4 * qd);
             }
-        } else {
-            // ---- at least one operand goes through registers (unaligned / ragged / synthesised)
-            if (kb == kq0) { pre0(); pre(0); }
+            QBM_STAMP(stamp0 + 3);
+        }
+    } else {
+        // ---- at least one operand goes through registers (unaligned / ragged / synthesised)
+        pre0();
+        pre(0);
+        for (int kb = kq0; kb < kq0 + Kq; kb += KP) {
+            const int klen = max(0, min(kend - kb, KP));
+            const int pieces = (klen + 15) >> 4;
             const int quads = (pieces + 3) >> 2;
             if constexpr (FAST_A) {
                 const rsrc_t ra = A.rsrc();
@@ -668,8 +684,8 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
             if constexpr (FAST_A || FAST_B) vm_wait(0);
             QBM_STAMP(stamp0 + 2);
             run(0, pieces);
+            QBM_STAMP(stamp0 + 3);
         }
-        QBM_STAMP(stamp0 + 3);
     }
 
     // partial strips -> LDS (each wave reuses the head of its own staging region), row-major
