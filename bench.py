@@ -178,37 +178,32 @@ def main():
             pass
         torch.cuda.synchronize()
 
-    # warm-up: at least W steps, through the launch path that is timed (whole graph replays when steps are captured)
-    warm_steps = args.warmup if graphs is None else -(-args.warmup // graphs[1]) * graphs[1]
-    run(warm_steps)
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dp:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert torch.isfinite(P.W).all(), "parameters diverged"
-
-    ms_per_step = dt / args.steps * 1e3
-    value = B * K_CD * args.steps * world / dt
-
-    # ---- roofline: per-kernel launch duration with HIP events on the launching stream ---------------
-    def time_kernel(fn, reps=200):
+    # ---- roofline, part 1: per-kernel launch duration with HIP events on the launching stream.  Runs BEFORE the timed
+    # region: its ~3000 launches also bring the GPU to its steady clock state, so that a short timed region (the driver
+    # times 20 steps = 0.6 ms) measures the same state a long one does ----------------------------------------------
+    def time_kernel(fn, reps=1000, per_graph=50):
+        """average duration of one launch, back to back: `per_graph` launches captured in a hipGraph (the host's launch
+        rate -- ~7 us per ctypes call -- would otherwise be what is measured), replayed reps / per_graph times between
+        two HIP events on the launching stream"""
         st = torch.cuda.current_stream()
-        for _ in range(20):
-            fn(cur())
+        sp = cur()
+        for _ in range(5):
+            fn(sp)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            sp_g = cur()
+            for _ in range(per_graph):
+                fn(sp_g)
+        g.replay()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)
-        for _ in range(reps):
-            fn(cur())
+        for _ in range(reps // per_graph):
+            g.replay()
         e1.record(st)
         e1.synchronize()
-        return e0.elapsed_time(e1) / reps * 1e-3
+        return e0.elapsed_time(e1) / (reps // per_graph * per_graph) * 1e-3
 
-    roofline = None
     if rank == 0:
         v0, y0 = data_v[0], data_y[0]
         ph0, h, vk, yk, phk = ws
@@ -228,6 +223,26 @@ def main():
                 4.0 * B * V * H + 4.0 * B * NC * H, 1),
         }
         timed = {k: time_kernel(f) for k, (f, _, _) in kernels.items()}
+
+    # warm-up: at least W steps, through the launch path that is timed (whole graph replays when steps are captured)
+    warm_steps = args.warmup if graphs is None else -(-args.warmup // graphs[1]) * graphs[1]
+    run(warm_steps)
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dp:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(P.W).all(), "parameters diverged"
+
+    ms_per_step = dt / args.steps * 1e3
+    value = B * K_CD * args.steps * world / dt
+
+    roofline = None
+    if rank == 0:
         dom = max(timed, key=lambda k: timed[k] * kernels[k][2])   # most time per CD-1 step
         # HBM bytes per launch of that kernel from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate
         # rocprofv3 --pmc passes: tools/gpu_profiles.sh -> profiles/rNN_pmc_traffic.json); null if absent

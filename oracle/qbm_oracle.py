@@ -150,17 +150,19 @@ def math(which: str, x) -> np.ndarray:
     return y
 
 
-def qgemm(A, B, nq=4) -> np.ndarray:
-    """[Q]: the contraction cut into nq chains (8: conditionals, 4: gradient blocks)"""
+def qgemm(A, B, nq=4, perm=None) -> np.ndarray:
+    """[Q]: the contraction cut into nq chains (8: conditionals, 4: gradient blocks); perm = piece order [Q'] (default: the
+    conditionals' order with 8 chains, ascending with 4)"""
+    perm = (nq == 8) if perm is None else perm
     A, B = _f32(A), _f32(B)
     M, K = A.shape
     K2, N = B.shape
     assert K == K2
     out = np.empty((M, N), np.float32)
     f = lib().orc_qgemm
-    f.argtypes = [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int]
+    f.argtypes = [_f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     f.restype = None
-    f(A, B, out, M, N, K, int(nq))
+    f(A, B, out, M, N, K, int(nq), int(bool(perm)))
     return out
 
 

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64 * H_NQ) void k_hidden(HiddenArgs a)
         }
     };
     QBM_STAMP(11);
-    const auto o = strip_mma<MT, NT, FAST, FAST, 1, NQ>(A, Bv, m0, n0, a.V, lds, a.KP, pre0, pre);
+    const auto o = strip_mma<MT, NT, FAST, FAST, 1, NQ, true>(A, Bv, m0, n0, a.V, lds, a.KP, pre0, pre);
     if (o.valid(0) && row < a.B && j0 < a.H) {
         float x = o.sum[0].x + dv, pv, hv = 0.f;
         if (MODE == 0) {
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(64 * V_NQ) void k_visible(VisibleArgs a)
         asm volatile("" : "+v"(uu[0]), "+v"(uu[1]));   // not sunk into the epilogue
     };
     QBM_STAMP(11);
-    const auto o = strip_mma<MT, NT, FAST, FAST, 2, NQ>(A, Bv, m0, n0, a.H, lds, a.KP, pre0, pre);
+    const auto o = strip_mma<MT, NT, FAST, FAST, 2, NQ, true>(A, Bv, m0, n0, a.H, lds, a.KP, pre0, pre);
     if (o.valid(0) && i < a.B && k0 < a.V) {
         const float sv[2] = {o.sum[0].x, o.sum[0].y};
         float pv[2], vv[2];

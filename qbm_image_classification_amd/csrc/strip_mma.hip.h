@@ -144,14 +144,23 @@ struct ViewCContig {
     int cols;
     int krows;  // number of k rows the buffer holds (its size is krows*ld*4 bytes)
     __device__ __forceinline__ rsrc_t rsrc() const { return make_rsrc(p, (unsigned)(krows * ld * 4)); }
+    // KPERM ([Q'] of the numerical contract): the image row that MFMA k-step s, lane group g reads (row 4s + g of a piece)
+    // holds k = 4g + s instead of k = 4s + g -- a different source row per lane, the same LDS image and reads
+    template <bool KPERM = false>
+    __device__ __forceinline__ static int krow(int r)   // r = image row 0..15 inside a piece -> k inside the piece
+    {
+        return KPERM ? 4 * (r & 3) + (r >> 2) : r;
+    }
+    template <bool KPERM = false>
     __device__ __forceinline__ DmaLane lane0(int c0, int kb, int lane) const
     {
-        const int c = c0 + 4 * (lane & 3), k = kb + (lane >> 2);
+        const int c = c0 + 4 * (lane & 3), k = kb + krow<KPERM>(lane >> 2);
         return DmaLane{c < cols ? (unsigned)((k * (int)ld + c) * 4) : kOOB, (unsigned)(64 * ld), k, 16};
     }
+    template <bool KPERM = false>
     __device__ __forceinline__ float4 get(int c0, int kb, int kend, int slot) const
     {
-        const int c = c0 + 4 * (slot & 3), k = kb + (slot >> 2);
+        const int c = c0 + 4 * (slot & 3), k = kb + 16 * (slot >> 6) + krow<KPERM>((slot >> 2) & 15);
         const float* q = p ? p + (long)min(k, max(kend - 1, 0)) * ld : g_zero16;
         const bool kok = p && k < kend;
         const int cm = p ? cols - 1 : 0;
@@ -278,6 +287,21 @@ struct ViewOnesRow {
     }
 };
 
+// lane walk / register-path value of a view, with the k rows of a piece permuted where the contract asks for it and the
+// image is row-per-k (fp32 "lin"); the K-contiguous images hold whole k groups per slot: the permutation is in how they are read
+template <bool KPERM, class V>
+__device__ __forceinline__ DmaLane view_lane0(const V& v, int r0, int kb, int lane)
+{
+    if constexpr (KPERM && !V::kK4 && sizeof(typename V::elem) == 4) return v.template lane0<true>(r0, kb, lane);
+    else return v.lane0(r0, kb, lane);
+}
+template <bool KPERM, class V>
+__device__ __forceinline__ auto view_get(const V& v, int r0, int kb, int kend, int slot)
+{
+    if constexpr (KPERM && !V::kK4 && sizeof(typename V::elem) == 4) return v.template get<true>(r0, kb, kend, slot);
+    else return v.get(r0, kb, kend, slot);
+}
+
 // ---- LDS budget ----------------------------------------------------------------------------------
 // bytes of one wave's staging region for panel length KP (multiple of 64): MT A tiles + NT fp32 B tiles,
 // and never smaller than the [16*MT][16*NT+4] fp32 partial strip that later reuses it
@@ -361,8 +385,14 @@ __device__ __forceinline__ void vm_wait(int n)
 // two wavefronts per SIMD, each with transfers, LDS reads and MFMAs of its own and no synchronisation before the partial
 // strips are combined: while one is parked on a transfer or an LDS read the other issues MFMAs, and the VALU work around
 // the contraction (Philox, sigmoid) issues at the two-wave rate.  (NQ is part of the numerical contract: [Q] in DESIGN.md.)
-template <int MT, int NT, bool FAST_A, bool FAST_B, int CPT = 4, int NQ = 4, class AView, class BView, class Pre0 = NoPre,
-          class Pre = NoPre>
+//
+// KPERM ([Q'] in DESIGN.md, the conditionals): inside every 16-k piece MFMA k-step s multiplies k = 4g + s (g = lane / 16)
+// instead of k = 4s + g, i.e. the chain visits k = 0,4,8,12, 1,5,9,13, ... of the piece.  A lane's four k-steps are then
+// ADJACENT in a K-contiguous image: one ds_read_b32 (u8: + v_cvt_f32_ubyte0..3) or one ds_read_b128 (fp32) per tile and
+// piece instead of four byte reads / two ds_read2st64; a row-per-k fp32 image is filled with its rows permuted (a per-lane
+// source address, free) and read as before.
+template <int MT, int NT, bool FAST_A, bool FAST_B, int CPT = 4, int NQ = 4, bool KPERM = false, class AView, class BView,
+          class Pre0 = NoPre, class Pre = NoPre>
 __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView& A, const BView& Bv, int m0, int n0, int K,
                                                                     char* __restrict__ lds, int KP, Pre0&& pre0 = NoPre{},
                                                                     Pre&& pre = NoPre{}, int stamp0 = 0)
@@ -373,6 +403,7 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
     const int qbm_diag = QBM_DIAG_MODE;   // 0 in the product: the diagnostic branches fold away
     constexpr bool A8 = sizeof(TA) == 1;
     constexpr bool A_K4 = AView::kK4, B_K4 = BView::kK4;
+    static_assert(!KPERM || A_K4, "the permuted contract is implemented for K-contiguous A operands (the conditionals)");
     constexpr int ASZ = (int)sizeof(TA);
     static_assert(sizeof(typename BView::elem) == 4, "the B operand is fp32");
     const int tid = threadIdx.x & (64 * NQ - 1);   // the thread's index inside its group of NQ wavefronts
@@ -396,9 +427,12 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
         for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     QBM_STAMP(stamp0 + 0);
 
-    const int fragB = (B_K4 ? ((lane & 15) * 4 + (lane >> 4)) : lane) * 4;                  // byte offset in a piece
-    const int fragA = A8 ? (A_K4 ? (lane & 15) * 16 + (lane >> 4) : (lane >> 4) * 16 * MT + (lane & 15))  // u8: see header
-                         : (A_K4 ? ((lane & 15) * 4 + (lane >> 4)) : lane) * 4;
+    // byte offset of this lane's fragment in a piece.  KPERM, K-contiguous images: the lane's 4 k-steps are the 4 bytes
+    // (u8: dword g of row r's 16-byte slot) or the 4 dwords (fp32: slot g*16 + r) it reads in one instruction
+    const int fragB = (KPERM && B_K4) ? ((lane >> 4) * 16 + (lane & 15)) * 16 : (B_K4 ? ((lane & 15) * 4 + (lane >> 4)) : lane) * 4;
+    const int fragA = KPERM ? (A8 ? (lane & 15) * 16 + (lane >> 4) * 4 : ((lane >> 4) * 16 + (lane & 15)) * 16)
+                    : A8    ? (A_K4 ? (lane & 15) * 16 + (lane >> 4) : (lane >> 4) * 16 * MT + (lane & 15))  // u8: see header
+                            : (A_K4 ? ((lane & 15) * 4 + (lane >> 4)) : lane) * 4;
 
     // ---- MFMA loop over one "quad" (up to 4 pieces = 64 k).
     // f32 MFMA runs at the vector rate and every VALU instruction of the wave displaces ~6-8 cycles of it (measured,
@@ -409,7 +443,8 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
     // ALL pending LDS-DMA (vmcnt(0)), stays out of the loop: the transfers of the following quads land under these
     // MFMAs.  The reads of piece p+1 are issued before the MFMAs of piece p behind counted lgkmcnt waits (LDS
     // returns in order; a wait after the first <= 15 reads of p+1 covers everything older).
-    constexpr int kReadsA = A8 ? 4 : 2, kReadsB = 2;
+    constexpr bool B_PERM = KPERM && B_K4;
+    constexpr int kReadsA = KPERM ? 1 : (A8 ? 4 : 2), kReadsB = B_PERM ? 1 : 2;
     constexpr int MT1 = (15 - kReadsB * NT) / kReadsA < MT ? (15 - kReadsB * NT) / kReadsA : MT;  // tiles in chunk 1
     constexpr int kChunk1 = kReadsB * NT + kReadsA * MT1;   // <= 15 = the largest lgkmcnt
     constexpr int kPieceA = A8 ? (A_TILES ? 256 * MT : 256) : 1024;   // bytes from piece to piece at one tile's base address
@@ -417,15 +452,17 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
         u32x2 a2[MT][2];     // fp32: k-steps (0,1) and (2,3)
         uint32_t a1[MT][4];  // u8: one zero-extended byte per k-step
         u32x2 b[NT][2];
+        uint32_t a4[MT];     // KPERM u8: the four k-steps in one dword
+        u32x4 a16[MT];       // KPERM fp32: the four k-steps
+        u32x4 b16[NT];       // KPERM, K-contiguous B
     };
     auto readA = [&](auto PC, uint32_t ad, int i, Frag& f) {
         constexpr int pc = decltype(PC)::value;
-#ifdef QBM_DIAG_NOREAD
-        for (int s = 0; s < 4; ++s) asm volatile("" : "=v"(f.a1[i][s]));
-        asm volatile("" : "=v"(f.a2[i][0])); asm volatile("" : "=v"(f.a2[i][1]));
-        return;
-#endif
-        if constexpr (A8) {
+        if constexpr (KPERM && A8) {
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f.a4[i]) : "v"(ad), "n"(pc * kPieceA) : "memory");
+        } else if constexpr (KPERM) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.a16[i]) : "v"(ad), "n"(pc * kPieceA) : "memory");
+        } else if constexpr (A8) {
             constexpr int st = A_K4 ? 4 : 64 * MT;   // k4 image: byte 4s+g of the row; lin image: 16-byte slot (4s+g)*MT + tile
             asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(f.a1[i][0]) : "v"(ad), "n"(pc * kPieceA) : "memory");
             asm volatile("ds_read_u8 %0, %1 offset:%2" : "=v"(f.a1[i][1]) : "v"(ad), "n"(pc * kPieceA + st) : "memory");
@@ -438,24 +475,32 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
     };
     auto readB = [&](auto PC, uint32_t ad, int t, Frag& f) {
         constexpr int pc = decltype(PC)::value;
-#ifdef QBM_DIAG_NOREAD
-        asm volatile("" : "=v"(f.b[t][0])); asm volatile("" : "=v"(f.b[t][1]));
-        return;
-#endif
-        asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(f.b[t][0]) : "v"(ad), "n"(4 * pc), "n"(4 * pc + 1) : "memory");
-        asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(f.b[t][1]) : "v"(ad), "n"(4 * pc + 2), "n"(4 * pc + 3) : "memory");
+        if constexpr (B_PERM) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.b16[t]) : "v"(ad), "n"(pc * 1024) : "memory");
+        } else {
+            asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(f.b[t][0]) : "v"(ad), "n"(4 * pc), "n"(4 * pc + 1) : "memory");
+            asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(f.b[t][1]) : "v"(ad), "n"(4 * pc + 2), "n"(4 * pc + 3) : "memory");
+        }
     };
     // the registers of `f` are valid after this (placed behind the wait that covers them): the widenings and MFMAs that
     // consume them cannot be scheduled above it
     auto tie = [&](Frag& f) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            asm volatile("" : "+v"(f.b[t][0]));
-            asm volatile("" : "+v"(f.b[t][1]));
+            if constexpr (B_PERM) {
+                asm volatile("" : "+v"(f.b16[t]));
+            } else {
+                asm volatile("" : "+v"(f.b[t][0]));
+                asm volatile("" : "+v"(f.b[t][1]));
+            }
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            if constexpr (A8) {
+            if constexpr (KPERM && A8) {
+                asm volatile("" : "+v"(f.a4[i]));
+            } else if constexpr (KPERM) {
+                asm volatile("" : "+v"(f.a16[i]));
+            } else if constexpr (A8) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(f.a1[i][s]));
             } else {
@@ -470,11 +515,9 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-#ifdef QBM_DIAG_NOCVT
-                if constexpr (A8) av[i][s] = __uint_as_float(f.a1[i][s]);
-#else
-                if constexpr (A8) av[i][s] = (float)f.a1[i][s];
-#endif
+                if constexpr (KPERM && A8) av[i][s] = (float)((f.a4[i] >> (8 * s)) & 0xffu);   // v_cvt_f32_ubyte<s>
+                else if constexpr (KPERM) av[i][s] = __uint_as_float(f.a16[i][s]);
+                else if constexpr (A8) av[i][s] = (float)f.a1[i][s];
                 else av[i][s] = __uint_as_float(f.a2[i][s >> 1][s & 1]);
             }
         if constexpr (A8) {   // the widenings as one burst in front of the MFMAs (no wait states between them)
@@ -487,7 +530,8 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][s], __uint_as_float(f.b[t][s >> 1][s & 1]), acc[i][t], 0, 0, 0);
+                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                        av[i][s], __uint_as_float(B_PERM ? f.b16[t][s] : f.b[t][s >> 1][s & 1]), acc[i][t], 0, 0, 0);
     };
     // the NP pieces of quad `qd`, straight-line (no branch inside: a merge point would cost register copies, and
     // copies are VALU work the MFMAs pay for)
@@ -561,10 +605,10 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 if constexpr (A_TILES) la[i] = A.template lane0_tiles<MT>(m0, kb, lane, i);   // instruction i of a quad
-                else la[i] = A.lane0(m0 + 16 * i, kb, lane);
+                else la[i] = view_lane0<KPERM>(A, m0 + 16 * i, kb, lane);
             }
 #pragma unroll
-            for (int t = 0; t < NT; ++t) lb[t] = Bv.lane0(n0 + 16 * t, kb, lane);
+            for (int t = 0; t < NT; ++t) lb[t] = view_lane0<KPERM>(Bv, n0 + 16 * t, kb, lane);
         };
         auto quad_pieces = [&](int qd) { return min(4, pieces - 4 * qd); };
         auto quad_dmas = [&](int qd) { return qd < quads ? (A8 ? MT : MT * quad_pieces(qd)) + NT * quad_pieces(qd) : 0; };
@@ -643,7 +687,7 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
                 for (int i = 0; i < MT; ++i) {
                     DmaLane la;
                     if constexpr (A_TILES) la = A.template lane0_tiles<MT>(m0, kb, lane, i);
-                    else la = A.lane0(m0 + 16 * i, kb, lane);
+                    else la = view_lane0<KPERM>(A, m0 + 16 * i, kb, lane);
                     for (int g = 0; g < (A8 ? quads : pieces); ++g) {
                         blds16(ra, (!A8 || la.k < kend) ? la.voff : kOOB, imgA + (A_TILES ? (g * MT + i) * 1024 : i * a_tile + g * 1024));
                         la.voff += la.step;
@@ -654,7 +698,7 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
                 for (int g = 0; g < quads; ++g)
 #pragma unroll
                     for (int i = 0; i < MT; ++i) {
-                        const uint4 v = A.get(m0 + 16 * i, kb, kend, g * 64 + lane);
+                        const uint4 v = view_get<KPERM>(A, m0 + 16 * i, kb, kend, g * 64 + lane);
                         if constexpr (A_TILES) reinterpret_cast<uint4*>(imgA)[(g * 64 + lane) * MT + i] = v;   // slot k*MT + tile
                         else reinterpret_cast<uint4*>(imgA + i * a_tile)[g * 64 + lane] = v;
                     }
@@ -662,13 +706,13 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
                 for (int pc = 0; pc < pieces; ++pc)
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
-                        reinterpret_cast<float4*>(imgA + i * a_tile)[pc * 64 + lane] = A.get(m0 + 16 * i, kb, kend, pc * 64 + lane);
+                        reinterpret_cast<float4*>(imgA + i * a_tile)[pc * 64 + lane] = view_get<KPERM>(A, m0 + 16 * i, kb, kend, pc * 64 + lane);
             }
             if constexpr (FAST_B) {
                 const rsrc_t rb = Bv.rsrc();
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    DmaLane lb = Bv.lane0(n0 + 16 * t, kb, lane);
+                    DmaLane lb = view_lane0<KPERM>(Bv, n0 + 16 * t, kb, lane);
                     for (int pc = 0; pc < pieces; ++pc) {
                         blds16(rb, lb.voff, imgB + t * b_tile + pc * 1024);
                         lb.voff += lb.step;
@@ -678,7 +722,7 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
                 for (int pc = 0; pc < pieces; ++pc)
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
-                        reinterpret_cast<float4*>(imgB + t * b_tile)[pc * 64 + lane] = Bv.get(n0 + 16 * t, kb, kend, pc * 64 + lane);
+                        reinterpret_cast<float4*>(imgB + t * b_tile)[pc * 64 + lane] = view_get<KPERM>(Bv, n0 + 16 * t, kb, kend, pc * 64 + lane);
             }
             QBM_STAMP(stamp0 + 1);
             if constexpr (FAST_A || FAST_B) vm_wait(0);

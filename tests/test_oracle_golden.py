@@ -46,15 +46,17 @@ def test_det_math_accuracy(oracle):
     assert np.isinf(oracle.math("softplus", np.array([100.0]))[0])
 
 
-@pytest.mark.parametrize("nq", [4, 8])
-def test_qgemm_is_split_fma_chain(oracle, nq):
-    """[Q]: nq contiguous chains of roundup16(ceil(K/nq)) terms, each an ascending fmaf chain, summed in chain order
-    (8 chains: the conditionals; 4: the gradient blocks)."""
+@pytest.mark.parametrize("nq,perm", [(4, False), (8, True), (8, False)])
+def test_qgemm_is_split_fma_chain(oracle, nq, perm):
+    """[Q]: nq contiguous chains of roundup16(ceil(K/nq)) terms, each an fmaf chain, summed in chain order (8 chains: the
+    conditionals; 4: the gradient blocks).  [Q']: the conditionals visit every aligned 16-term piece in the order
+    0,4,8,12, 1,5,9,13, 2,6,10,14, 3,7,11,15 (terms beyond K skipped); the gradient in ascending order."""
+    order = [4 * (j & 3) + (j >> 2) for j in range(16)] if perm else list(range(16))
     rs = np.random.RandomState(0)
     for (M, N, K) in [(3, 5, 16), (2, 4, 9), (4, 3, 784), (1, 2, 1), (2, 2, 5), (2, 3, 100), (2, 2, 512)]:
         A = rs.standard_normal((M, K)).astype(np.float32)
         B = rs.standard_normal((K, N)).astype(np.float32)
-        got = oracle.qgemm(A, B, nq)
+        got = oracle.qgemm(A, B, nq, perm)
         Kq = ((K + nq - 1) // nq + 15) // 16 * 16
         want = np.zeros((M, N), np.float32)
         for m in range(M):
@@ -62,7 +64,8 @@ def test_qgemm_is_split_fma_chain(oracle, nq):
                 parts = []
                 for q in range(nq):
                     acc = np.float32(0)
-                    for k in range(q * Kq, min(K, (q + 1) * Kq)):
+                    k1 = min(K, (q + 1) * Kq)
+                    for k in (p0 + j for p0 in range(q * Kq, k1, 16) for j in order if p0 + j < k1):
                         # exact fma in float64: a*b is exact (48 bits), the sum is rounded once to
                         # 53 bits and again to 24 -- double rounding can differ only on ties
                         acc = np.float32(np.float64(A[m, k]) * np.float64(B[k, n]) + np.float64(acc))
