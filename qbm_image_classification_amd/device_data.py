@@ -4,8 +4,10 @@ The reference moves the whole training set to the device and lets `torch.utils.d
 slice it on the host side (`rbm_main.py:70-74`); every step then pays host-side indexing, and binary data
 travel as fp32.  `DeviceDataset` keeps the set in HBM in its smallest exact form (fp32 greyscale, uint8 {0,1},
 or bit-packed: 98 bytes per 28x28 image), makes the epoch permutation on the device (stable argsort of
-Philox keys: the same permutation for any rank count) and delivers a minibatch with ONE HIP gather launch
-(rows + int32 labels + one-hot labels).  Iterating it yields `(batch, labels)` like the reference's loader,
+Philox keys: the same permutation for any rank count) and delivers the minibatches of an epoch with ONE HIP gather
+launch per epoch (rows + int32 labels + one-hot labels of all of this rank's rows, in epoch order: 47 MB for MNIST as
+uint8 -- HBM is 288 GB; the minibatches are then contiguous slices of it and a training step pays no launch for its
+data) or, with `epoch_gather=False`, one gather launch per minibatch.  Iterating it yields `(batch, labels)` like the reference's loader,
 so `ClassificationRBM.train_rbm(train_loader=DeviceDataset(...))` runs unchanged, with no host copy per step.
 
 There is no CPU fallback: the HIP library must be present (`_lib.load()` raises otherwise).
@@ -74,12 +76,14 @@ class DeviceDataset:
     out: "f32" or "u8" -- dtype of the delivered minibatch (u8 only for binary storage).
     shuffle/seed: epoch e uses the permutation `HipDataOps.permutation(seed, e, N)`; the epoch counter advances
              with every full iteration.
+    epoch_gather: True (default) = one gather launch per epoch into a buffer of this rank's rows, minibatches are slices
+             of it; False = one gather launch per minibatch (smallest footprint).  Same values either way.
     rank/world: data parallelism -- every rank walks the same global batches of `batch_size * world` rows and takes
              rows [rank*batch_size, (rank+1)*batch_size) of each, so the union over ranks is the single-process batch.
     """
 
     def __init__(self, x, y, batch_size, num_classes, storage="f32", out=None, shuffle=True, seed=44, threshold=0.5,
-                 drop_last=False, device="cuda:0", rank=0, world=1, ops=None):
+                 drop_last=False, device="cuda:0", rank=0, world=1, ops=None, epoch_gather=True):
         if storage not in ("f32", "u8", "bits"):
             raise ValueError("storage must be 'f32', 'u8' or 'bits'")
         self.ops = ops if ops is not None else HipDataOps(device)
@@ -90,6 +94,7 @@ class DeviceDataset:
         self.num_classes = int(num_classes)
         self.batch_size, self.shuffle, self.seed, self.drop_last = int(batch_size), bool(shuffle), int(seed), bool(drop_last)
         self.rank, self.world = int(rank), int(world)
+        self.epoch_gather = bool(epoch_gather)
         self.epoch = 0
         self.labels = torch.as_tensor(np.asarray(y) if not torch.is_tensor(y) else y).reshape(-1).to(dev, torch.int32).contiguous()
         if self.labels.numel() != self.N:
@@ -125,6 +130,23 @@ class DeviceDataset:
         """Yield (x[B,V], labels int32 [B], onehot [B,C] or None) for this rank."""
         order = self.order(epoch)
         g = self.batch_size * self.world
+        if self.epoch_gather:
+            # this rank's rows of every global batch, in epoch order: positions p with (p mod g) in [rank*B, (rank+1)*B)
+            n_used = len(self) * g if self.drop_last else self.N
+            mine = order[:min(n_used, self.N)]
+            if self.world > 1:
+                pos = torch.arange(mine.numel(), device=mine.device) % g
+                mine = mine[(pos >= self.rank * self.batch_size) & (pos < (self.rank + 1) * self.batch_size)]
+            X, L, O = (self.ops.gather(self.data, self.kind, mine, self.V, self.out_kind, self.labels, self.num_classes, want_onehot)
+                       if mine.numel() else (torch.empty(0, self.V, dtype=torch.float32 if self.out_kind == QBM_F32 else torch.uint8,
+                                                         device=self.ops.device), torch.empty(0, dtype=torch.int32, device=self.ops.device), None))
+            at = 0
+            for k in range(len(self)):
+                lo = k * g + self.rank * self.batch_size
+                n = max(0, min(lo + self.batch_size, min((k + 1) * g, self.N)) - lo)
+                yield X[at:at + n], L[at:at + n], (O[at:at + n] if O is not None else None)
+                at += n
+            return
         for k in range(len(self)):
             lo = k * g + self.rank * self.batch_size
             hi = min(lo + self.batch_size, min((k + 1) * g, self.N))

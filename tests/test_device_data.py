@@ -35,13 +35,14 @@ def test_oracle_gather_unpacks_the_mnist_fixture(oracle):
 
 
 @pytest.mark.parametrize("storage,out", [("f32", "f32"), ("u8", "u8"), ("bits", "u8"), ("bits", "f32")])
-def test_device_dataset_host_logic(oracle, storage, out):
+@pytest.mark.parametrize("eg", [True, False], ids=["gather-per-epoch", "gather-per-batch"])
+def test_device_dataset_host_logic(oracle, storage, out, eg):
     from oracle_backends import OracleDataOps
     from qbm_image_classification_amd.device_data import DeviceDataset
 
     x, y = _set()
     want = x if storage == "f32" else (x > 0.5).astype(np.float32)
-    ds = DeviceDataset(x, y, batch_size=8, num_classes=3, storage=storage, out=out, seed=9, ops=OracleDataOps())
+    ds = DeviceDataset(x, y, batch_size=8, num_classes=3, storage=storage, out=out, seed=9, ops=OracleDataOps(), epoch_gather=eg)
     assert len(ds) == 5 and ds.epoch == 0
     seen = []
     for ep in range(2):
@@ -54,19 +55,19 @@ def test_device_dataset_host_logic(oracle, storage, out):
         seen.append(perm)
     assert not np.array_equal(seen[0], seen[1])
     # two ranks together deliver exactly the single-process batches of 16
-    whole = DeviceDataset(x, y, batch_size=16, num_classes=3, storage=storage, out=out, seed=9, ops=OracleDataOps())
-    r0 = DeviceDataset(x, y, batch_size=8, num_classes=3, storage=storage, out=out, seed=9, rank=0, world=2, ops=OracleDataOps())
-    r1 = DeviceDataset(x, y, batch_size=8, num_classes=3, storage=storage, out=out, seed=9, rank=1, world=2, ops=OracleDataOps())
+    whole = DeviceDataset(x, y, batch_size=16, num_classes=3, storage=storage, out=out, seed=9, ops=OracleDataOps(), epoch_gather=eg)
+    r0 = DeviceDataset(x, y, batch_size=8, num_classes=3, storage=storage, out=out, seed=9, rank=0, world=2, ops=OracleDataOps(), epoch_gather=eg)
+    r1 = DeviceDataset(x, y, batch_size=8, num_classes=3, storage=storage, out=out, seed=9, rank=1, world=2, ops=OracleDataOps(), epoch_gather=eg)
     assert len(whole) == len(r0) == len(r1) == 3
     for (xw, lw, ow), (x0, l0, _), (x1, l1, _) in zip(whole.batches(0, True), r0.batches(0), r1.batches(0)):
         assert torch.equal(xw, torch.cat([x0, x1])) and torch.equal(lw, torch.cat([l0, l1]))
         assert torch.equal(ow.argmax(1).int(), lw)
     assert [len(b[0]) for b in r1.batches(0)] == [8, 8, 0]      # 37 = 16 + 16 + 5: the last global batch holds 5 rows
     # no shuffle, drop_last
-    plain = DeviceDataset(x, y, batch_size=8, num_classes=3, storage=storage, out=out, shuffle=False, drop_last=True, ops=OracleDataOps())
+    plain = DeviceDataset(x, y, batch_size=8, num_classes=3, storage=storage, out=out, shuffle=False, drop_last=True, ops=OracleDataOps(), epoch_gather=eg)
     assert len(plain) == 4 and np.array_equal(next(iter(plain))[1].numpy(), y[:8])
     with pytest.raises(ValueError):
-        DeviceDataset(x, y, batch_size=8, num_classes=3, storage="f32", out="u8", ops=OracleDataOps())
+        DeviceDataset(x, y, batch_size=8, num_classes=3, storage="f32", out="u8", ops=OracleDataOps(), epoch_gather=eg)
 
 
 # ---- GPU: HIP entry points vs the oracle ---------------------------------------------------------------------

@@ -83,7 +83,7 @@ def main():
             ops.cd_step(P, G, xb, one, 1, 7, (rep * len(ds) + k) * 4, 0, None, None, True, 0.05, 1.0, float(B), 0.0, ws)
         torch.cuda.synchronize(); dt = min(dt, time.perf_counter() - t0)
     out.append({"what": f"epoch of {N} bit-packed images ({ds.bytes_resident() / 1e6:.1f} MB resident), CD-1 784x512 B=256, "
-                        "device permutation + gather per step", "ms_per_epoch": round(dt * 1e3, 2),
+                        "device permutation + one gather launch per epoch", "ms_per_epoch": round(dt * 1e3, 2),
                 "us_per_step": round(dt / len(ds) * 1e6, 2), "images_per_s": round(N / dt, 1)})
     print(json.dumps(out[-1]), flush=True)
     # greedy k-center coreset at the size config #5 draws from (MNIST 0/1 train split, 256-d hidden means)
