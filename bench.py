@@ -87,10 +87,12 @@ def main():
     lr, factor, sparse = 0.05, 1.0, 0.0
 
     # steps per captured graph: the requested size, or -- when it does not divide the timed step count -- the largest
-    # divisor of it up to 32, so that a short timed region (the driver runs a few tens of steps) is whole graph replays
-    # rather than a tail of host-bound eager launches
+    # divisor of it up to 16, so that a short timed region (the driver runs a few tens of steps) is whole graph replays
+    # rather than a tail of host-bound eager launches (measured for 20 steps: graphs of 10 -> 30.7 us per step, of 20 ->
+    # 31.0, of 5 -> 31.3, of 2 -> 32.8; 2000 steps in graphs of 8 -> 29.8: a region this short also pays for the idle
+    # gap the synchronize in front of it leaves on the device)
     if args.graph > 0 and args.steps % args.graph != 0:
-        divs = [d for d in range(2, 33) if args.steps % d == 0]
+        divs = [d for d in range(2, 17) if args.steps % d == 0]
         if divs:
             args.graph = divs[-1]
     # ---- synthetic minibatches, resident in HBM ----------------------------------------------------
