@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void k_batch_stats(const double* __restrict__ 
 
 // x-dependent part of create_qubo_matrix_from (src/model/faster_dqbm.py:236-245, 273-283): float64,
 // sequential over k, one thread per (image, variable); rounded to fp32 for the sampler.
-__global__ __launch_bounds__(256) void k_linear_fields(const double* __restrict__ X, const int* __restrict__ labels,
+__global__ __launch_bounds__(64) void k_linear_fields(const double* __restrict__ X, const int* __restrict__ labels,
                                                        const double* __restrict__ W_vh, const double* __restrict__ W_vo,
                                                        const double* __restrict__ b_h, double b_o_val,
                                                        const double* __restrict__ b_o_dev, int B, int D, int H,
@@ -291,13 +291,32 @@ __global__ __launch_bounds__(256) void k_linear_fields(const double* __restrict_
     const double* x = X + (long)i * D;
     double a = 0.0;
     if (!labels && v == 0) {
-        for (int k = 0; k < D; ++k) a += x[k] * W_vo[k];
+        int k = 0;
+        for (; k + 8 <= D; k += 8) {
+            double xv[8], wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { xv[u] = x[k + u]; wv[u] = W_vo[k + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += xv[u] * wv[u];
+        }
+        for (; k < D; ++k) a += x[k] * W_vo[k];
         lin[idx] = (float)((b_o + a) / beta_eff);
         return;
     }
     const int j = labels ? v : v - 1;
     if (labels) a += (double)labels[i] * W_vh[j];
-    for (int k = 0; k < D; ++k) a += x[k] * W_vh[(long)(1 + k) * H + j];
+    // the sum runs over k in ascending order (product, then sum); the operands of 8 terms are requested together so that
+    // their latencies overlap instead of adding up
+    const double* w = W_vh + (long)H + j;
+    int k = 0;
+    for (; k + 8 <= D; k += 8) {
+        double xv[8], wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { xv[u] = x[k + u]; wv[u] = w[(long)(k + u) * H]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += xv[u] * wv[u];
+    }
+    for (; k < D; ++k) a += x[k] * w[(long)k * H];
     lin[idx] = (float)((b_h[j] + a) / beta_eff);
 }
 
@@ -308,19 +327,18 @@ __global__ __launch_bounds__(256) void k_linear_fields(const double* __restrict_
 __host__ __device__ inline long qbm_theta_len(int D, int H) { return (long)(1 + D) * H + D + H + 1; }
 
 // Image-independent couplings of the QUBO (create_qubo_matrix_from, :242-243 clamped, :256-271 unclamped) as the sampler
-// wants them: symmetric fp32 J with zero diagonal, J_ab = fp32(Q_ab / beta_eff) of the upper-triangular Q.  One thread per
-// row; also the row's sum of |J| (float64, ascending columns) and its smallest non-zero |J| (0 if none): the
-// coefficient statistics of the annealing range (k_qbm_beta).
-__global__ __launch_bounds__(256) void k_qbm_couplings(const double* __restrict__ w_label /* W_vh row 0: [H], unclamped only */,
-                                                       const double* __restrict__ W_hh /* [H,H] upper triangle, or null */,
-                                                       int H, int clamped, double beta_eff, float* __restrict__ J,
-                                                       double* __restrict__ rowabs, double* __restrict__ rowmin)
+// wants them: symmetric fp32 J with zero diagonal, J_ab = fp32(Q_ab / beta_eff) of the upper-triangular Q.  One wavefront
+// per row: the lanes write the row's entries, lane 0 then adds their magnitudes in ascending column order (float64) for
+// the row's sum of |J|; the smallest non-zero |J| of the row (0 if none) is order-independent.  Both feed k_qbm_beta.
+__global__ __launch_bounds__(64) void k_qbm_couplings(const double* __restrict__ w_label /* W_vh row 0: [H], unclamped only */,
+                                                      const double* __restrict__ W_hh /* [H,H] upper triangle, or null */,
+                                                      int H, int clamped, double beta_eff, float* __restrict__ J,
+                                                      double* __restrict__ rowabs, double* __restrict__ rowmin)
 {
+    __shared__ float mag[QBM_MAX_QUBO_VARS];
     const int n = clamped ? H : H + 1, o = clamped ? 0 : 1;
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= n) return;
-    double sum = 0.0, mn = 0.0;
-    for (int b = 0; b < n; ++b) {
+    const int a = blockIdx.x, lane = threadIdx.x;
+    for (int b = lane; b < n; b += 64) {
         float v = 0.f;
         if (a != b) {
             if (!clamped && (a == 0 || b == 0)) v = (float)(w_label[(a == 0 ? b : a) - 1] / beta_eff);
@@ -330,7 +348,13 @@ __global__ __launch_bounds__(256) void k_qbm_couplings(const double* __restrict_
             }
         }
         J[(long)a * n + b] = v;
-        const double av = fabs((double)v);
+        mag[b] = __builtin_fabsf(v);
+    }
+    __syncthreads();
+    if (lane != 0) return;
+    double sum = 0.0, mn = 0.0;
+    for (int b = 0; b < n; ++b) {
+        const double av = (double)mag[b];
         sum += av;
         if (av > 0.0 && (mn == 0.0 || av < mn)) mn = av;
     }
@@ -524,7 +548,8 @@ int qbm_qbm_couplings(const double* w_label, const double* W_hh, int H, int clam
     if (!J || !rowabs || !rowmin || (!clamped && !w_label)) return fail(QBM_ERR_ARG, "couplings: null buffer");
     if (beta_eff == 0.0) return fail(QBM_ERR_ARG, "couplings: beta_eff == 0");
     const int n = clamped ? H : H + 1;
-    hipLaunchKernelGGL(k_qbm_couplings, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_label, W_hh, H, clamped,
+    if (n > QBM_MAX_QUBO_VARS) return fail(QBM_ERR_ARG, "couplings: more than QBM_MAX_QUBO_VARS variables");
+    hipLaunchKernelGGL(k_qbm_couplings, dim3(n), dim3(64), 0, (hipStream_t)stream, w_label, W_hh, H, clamped,
                        beta_eff, J, rowabs, rowmin);
     QBM_CHECK_LAUNCH("k_qbm_couplings");
     return QBM_OK;
@@ -577,7 +602,7 @@ int qbm_qbm_linear_fields_dev(const double* X, const int32_t* labels, const doub
     const double* W_vo = W_vh + (long)(1 + D) * H;
     const double* b_h = W_vo + D;
     const int n = labels ? H : H + 1;
-    hipLaunchKernelGGL(k_linear_fields, dim3((B * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, X, labels, W_vh,
+    hipLaunchKernelGGL(k_linear_fields, dim3((B * n + 63) / 64), dim3(64), 0, (hipStream_t)stream, X, labels, W_vh,
                        W_vo, b_h, 0.0, b_h + H, B, D, H, beta_eff, lin);
     QBM_CHECK_LAUNCH("k_linear_fields");
     return QBM_OK;
@@ -593,7 +618,7 @@ int qbm_qbm_linear_fields(const double* X, const int32_t* labels, const double* 
     if (!X || !W_vh || !W_vo || !b_h || !lin) return fail(QBM_ERR_ARG, "linear_fields: null buffer");
     if (beta_eff == 0.0) return fail(QBM_ERR_ARG, "linear_fields: beta_eff == 0");
     const int n = labels ? H : H + 1;
-    hipLaunchKernelGGL(k_linear_fields, dim3((B * n + 255) / 256), dim3(256), 0, (hipStream_t)stream, X, labels, W_vh,
+    hipLaunchKernelGGL(k_linear_fields, dim3((B * n + 63) / 64), dim3(64), 0, (hipStream_t)stream, X, labels, W_vh,
                        W_vo, b_h, b_o, (const double*)nullptr, B, D, H, beta_eff, lin);
     QBM_CHECK_LAUNCH("k_linear_fields");
     return QBM_OK;
