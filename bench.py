@@ -208,7 +208,7 @@ def main():
 
     if rank == 0:
         v0, y0 = data_v[0], data_y[0]
-        ph0, h, vk, yk, phk = ws
+        ph0, h, vk, yk, phk = ws[:5]
         ng = _lib.RbmGrads(None, ptr(G.gb), ptr(G.gd), ptr(G.gU), ptr(G.gc))
         scratchW = P.W.clone()
         kernels = {

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QBM_ABI_VERSION 8
+#define QBM_ABI_VERSION 9
 #define QBM_MAX_CLASSES 15 /* class rows + the bias row share one 16-row gradient tile */
 #define QBM_MAX_QUBO_VARS 1024
 
@@ -146,14 +146,23 @@ typedef struct {
     uint8_t* vk;  /* [B,V] */
     float* yk;    /* [B,C] one-hot */
     float* phk;   /* [B,H] */
+    uint32_t* sync; /* [QBM_CD_SYNC_WORDS] uint32, zeroed once by the caller and then left alone, or NULL: state of the
+                     * fused chain kernel (round flags of its XCD-local barriers, the XCC ids, status word at index 512:
+                     * 0 = fine, 1 = a barrier timed out, 2 = workgroups of a row block on different XCDs -> results of
+                     * that launch are invalid, run with QBM_FUSED_CHAIN=0).  NULL = always the launch-per-phase path.
+                     * One buffer per stream of concurrent work. */
 } qbm_rbm_cd_workspace;
+#define QBM_CD_SYNC_WORDS 576
 
 /* k-step block-Gibbs chain (declared, never implemented in the reference:
  * src/ClassificationRBM.py:19, :179-182).  v0[B,V] fp32 or uint8 (v0_dtype), y0[B,C] fp32.
  * Draw ids: h_0 -> offset; t = 1..k: v_t -> offset+3t-2, y_t -> offset+3t-1, h_t -> offset+3t.
  * chain_v (uint8 [B,V]) / chain_y (fp32 [B,C]) non-NULL = persistent chains (PCD): the negative chain
  * starts from them and the k-th Gibbs iteration writes (v_k, y_k) straight into them; ws->vk / ws->yk then hold
- * the states of iteration k-1 (untouched for k = 1). */
+ * the states of iteration k-1 (untouched for k = 1).
+ * With ws->sync set, uint8 data and B a multiple of 32 up to 256 (H <= 512, V <= 1024, C <= 12, 16-byte aligned
+ * operands) the whole chain is ONE launch (row blocks of 32 pinned to one XCD each, XCD-local barriers between the
+ * phases); same draws, same bits. */
 QBM_API int qbm_rbm_cd_chain(const qbm_rbm_params* P, const void* v0, int v0_dtype, const float* y0, int B, int k,
                              uint64_t seed, uint64_t offset, uint32_t row0, uint8_t* chain_v, float* chain_y,
                              const qbm_rbm_cd_workspace* ws, void* stream);

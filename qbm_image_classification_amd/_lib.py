@@ -8,7 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libqbm_hip.so")
 
-QBM_ABI_VERSION = 8
+QBM_ABI_VERSION = 9
 QBM_MAX_CLASSES = 15
 QBM_F32, QBM_U8 = 0, 1
 
@@ -27,7 +27,11 @@ class RbmGrads(C.Structure):
 
 
 class CdWorkspace(C.Structure):
-    _fields_ = [("ph0", C.c_void_p), ("h", C.c_void_p), ("vk", C.c_void_p), ("yk", C.c_void_p), ("phk", C.c_void_p)]
+    _fields_ = [("ph0", C.c_void_p), ("h", C.c_void_p), ("vk", C.c_void_p), ("yk", C.c_void_p), ("phk", C.c_void_p),
+                ("sync", C.c_void_p)]   # state of the fused chain kernel (QBM_CD_SYNC_WORDS uint32, zeroed once) or None
+
+
+QBM_CD_SYNC_WORDS = 576
 
 
 class DiscWorkspace(C.Structure):

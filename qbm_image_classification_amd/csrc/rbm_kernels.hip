@@ -54,10 +54,12 @@ template <class T> struct CView;   // M-contiguous A operand of element type T
 template <> struct CView<float> { using type = ViewCContig; };
 template <> struct CView<uint8_t> { using type = ViewCContigU8; };
 
-template <class T>
+// SC1: an L1-bypassing load (the state was written by another workgroup of the XCD during this launch)
+template <class T, bool SC1 = false>
 __device__ __forceinline__ float ld_state(const void* p, long i)
 {
-    return (float)reinterpret_cast<const T*>(p)[i];
+    if constexpr (SC1) return (float)__hip_atomic_load(reinterpret_cast<const T*>(p) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return (float)reinterpret_cast<const T*>(p)[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -89,20 +91,14 @@ constexpr int H_NQ = 8;
 // FASTK: 0 = operands through registers (any shape), 1 = LDS-DMA operands, 2 = LDS-DMA operands and epilogue operands
 // (a compile-time choice: the hooks below must not hold both variants, or the compiler's merge of the two waits for the
 // first operand transfers inside the hook)
-template <class TA, int FASTK, int MODE, int CM>
-__global__ __launch_bounds__(64 * H_NQ) void k_hidden(HiddenArgs a)
+// AUX: cache policy of the loads of v and y (kSc1 inside the fused chain kernel: another workgroup of the XCD wrote them
+// during this launch; FASTK == 2 only).  The body of strip (ms, ns); the caller is a 512-thread workgroup.
+template <class TA, int FASTK, int MODE, int CM, int AUX = 0>
+__device__ __forceinline__ void hidden_body(const HiddenArgs& a, int ms, int ns, char* lds)
 {
     constexpr bool FAST = FASTK >= 1;
+    static_assert(AUX == 0 || FASTK == 2, "cache policies apply to the all-DMA variant");
     constexpr int MT = H_MT, NT = H_NT, NQ = H_NQ;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    QBM_STAMP(10);
-    // every kernel argument in ONE round trip to the (cold) scalar cache: the compiler otherwise fetches them where they
-    // are first used, one dependent s_load latency after the other in front of the first operand transfer
-    asm volatile("" ::"s"(a.v), "s"(a.y), "s"(a.W), "s"(a.d), "s"(a.U), "s"(a.p), "s"(a.s), "s"(a.s8), "s"(a.B), "s"(a.V),
-                 "s"(a.H), "s"(a.C), "s"(a.KP), "s"(a.seed), "s"(a.offset), "s"(a.row0));
-    const int nM = (a.B + 16 * MT - 1) / (16 * MT), nN = (a.H + 16 * NT - 1) / (16 * NT);
-    int ms, ns;
-    strip_coords(nM, nN, ms, ns);
     const int m0 = ms * 16 * MT, n0 = ns * 16 * NT;
     const typename KView<TA>::type A{reinterpret_cast<const TA*>(a.v), a.V, a.B};
     const ViewCContig Bv{a.W, a.H, a.H, a.V};
@@ -146,7 +142,7 @@ __global__ __launch_bounds__(64 * H_NQ) void k_hidden(HiddenArgs a)
                 const int col = n0 + 4 * (lane - nU - nY);
                 if (col < a.H) src = a.d + col;
             }
-            if (src) __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)cls_lds, 16, 0, 0);
+            if (src) __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)cls_lds, 16, 0, AUX);
         } else {
             d_g = a.d[j_c];
             if (with_cls) {
@@ -209,7 +205,7 @@ __global__ __launch_bounds__(64 * H_NQ) void k_hidden(HiddenArgs a)
         }
     };
     QBM_STAMP(11);
-    const auto o = strip_mma<MT, NT, FAST, FAST, 1, NQ, true>(A, Bv, m0, n0, a.V, lds, a.KP, pre0, pre);
+    const auto o = strip_mma<MT, NT, FAST, FAST, 1, NQ, true, AUX>(A, Bv, m0, n0, a.V, lds, a.KP, pre0, pre);
     if (o.valid(0) && row < a.B && j0 < a.H) {
         float x = o.sum[0].x + dv, pv, hv = 0.f;
         if (MODE == 0) {
@@ -227,6 +223,21 @@ __global__ __launch_bounds__(64 * H_NQ) void k_hidden(HiddenArgs a)
     QBM_STAMP(12);
 }
 
+template <class TA, int FASTK, int MODE, int CM>
+__global__ __launch_bounds__(64 * H_NQ) void k_hidden(HiddenArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    QBM_STAMP(10);
+    // every kernel argument in ONE round trip to the (cold) scalar cache: the compiler otherwise fetches them where they
+    // are first used, one dependent s_load latency after the other in front of the first operand transfer
+    asm volatile("" ::"s"(a.v), "s"(a.y), "s"(a.W), "s"(a.d), "s"(a.U), "s"(a.p), "s"(a.s), "s"(a.s8), "s"(a.B), "s"(a.V),
+                 "s"(a.H), "s"(a.C), "s"(a.KP), "s"(a.seed), "s"(a.offset), "s"(a.row0));
+    const int nM = (a.B + 16 * H_MT - 1) / (16 * H_MT), nN = (a.H + 16 * H_NT - 1) / (16 * H_NT);
+    int ms, ns;
+    strip_coords(nM, nN, ms, ns);
+    hidden_body<TA, FASTK, MODE, CM>(a, ms, ns, lds);
+}
+
 // ---------------------------------------------------------------------------------------------
 // A-3  sample_class  (src/ClassificationRBM.py:54-60): exp(h.U^T + c), L1-normalised (eps 1e-12);
 // categorical draw: one uniform per row, first class whose running sum exceeds u.
@@ -234,15 +245,18 @@ __global__ __launch_bounds__(64 * H_NQ) void k_hidden(HiddenArgs a)
 // exactly as one wave would do it), the energies meet in LDS (`e_s`, QBM_MAX_CLASSES floats) and thread 0 normalises
 // and draws.  All loads are unconditional.
 // ---------------------------------------------------------------------------------------------
-template <class TH, int CM>
-__device__ __forceinline__ void class_row(const void* __restrict__ h, const float* __restrict__ U,
-                                          const float* __restrict__ cb, float* __restrict__ p_out,
-                                          float* __restrict__ y_out, int i, int H, int C, uint64_t seed,
-                                          uint64_t offset, uint32_t row0, float* __restrict__ e_s)
+// class_row_energies: the 4 wavefronts of a 256-thread team (tid = 0..255) fill e_s[c] = exp(h.U_c + c_c); class_row_draw:
+// the team's thread 0 normalises and draws.  A workgroup barrier stands between the two (class_row = both, for a
+// 256-thread team that is alone in its workgroup).  `active` = false: the team has no row in this round (it only keeps
+// the workgroup's barrier count).
+template <class TH, int CM, bool SC1 = false>
+__device__ __forceinline__ void class_row_energies(const void* __restrict__ h, const float* __restrict__ U,
+                                                   const float* __restrict__ cb, int i, int H, int C, int tid,
+                                                   float* __restrict__ e_s)
 {
     constexpr int CW = (CM + 3) / 4;   // classes per wave
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     float e[CW], cbv[CW];
 #pragma unroll
     for (int t = 0; t < CW; ++t) { e[t] = 0.f; cbv[t] = cb[min(w + 4 * t, C - 1)]; }
@@ -254,7 +268,7 @@ __device__ __forceinline__ void class_row(const void* __restrict__ h, const floa
         for (int t = 0; t < 4; ++t) {
             const int j = jb + t * kWave + lane;
             const int jj = min(j, H - 1);
-            const float x = ld_state<TH>(h, (long)i * H + jj);
+            const float x = ld_state<TH, SC1>(h, (long)i * H + jj);
             hv[t] = (j < H) ? x : 0.f;
 #pragma unroll
             for (int c = 0; c < CW; ++c) uv[t][c] = U[(long)min(w + 4 * c, C - 1) * H + jj];
@@ -269,8 +283,12 @@ __device__ __forceinline__ void class_row(const void* __restrict__ h, const floa
         const float v = det_expf(wave_butterfly_sum(e[t]) + cbv[t]);
         if (lane == 0 && w + 4 * t < C) e_s[w + 4 * t] = v;
     }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
+}
+
+template <int CM>
+__device__ __forceinline__ void class_row_draw(float* __restrict__ p_out, float* __restrict__ y_out, int i, int C,
+                                               uint64_t seed, uint64_t offset, uint32_t row0, const float* __restrict__ e_s)
+{
     float ev[CM];
 #pragma unroll
     for (int c = 0; c < CM; ++c) ev[c] = e_s[min(c, C - 1)];
@@ -294,6 +312,17 @@ __device__ __forceinline__ void class_row(const void* __restrict__ h, const floa
     }
     if (y_out)
         for (int c = 0; c < C; ++c) y_out[(long)i * C + c] = (c == pick) ? 1.f : 0.f;
+}
+
+template <class TH, int CM>
+__device__ __forceinline__ void class_row(const void* __restrict__ h, const float* __restrict__ U,
+                                          const float* __restrict__ cb, float* __restrict__ p_out,
+                                          float* __restrict__ y_out, int i, int H, int C, uint64_t seed,
+                                          uint64_t offset, uint32_t row0, float* __restrict__ e_s)
+{
+    class_row_energies<TH, CM>(h, U, cb, i, H, C, (int)threadIdx.x, e_s);
+    __syncthreads();
+    if (threadIdx.x == 0) class_row_draw<CM>(p_out, y_out, i, C, seed, offset, row0, e_s);
 }
 
 template <class TH, int CM>
@@ -334,27 +363,17 @@ struct VisibleArgs {
 // 8 wavefronts (512 threads) per strip workgroup: wavefront q contracts chain q of the 8 the K = H terms are cut into
 // ([Q] with NQ = 8); two visible units per thread in the epilogue.
 constexpr int V_NQ = 8;
-template <class TA, bool FAST, int CM>
-__global__ __launch_bounds__(64 * V_NQ) void k_visible(VisibleArgs a)
+// The body of strip (ms, ns) of (16 MT) x (16 NT) outputs; the caller is a 512-thread workgroup.  AUX: cache policy of the
+// loads of h (kSc1 inside the fused chain kernel).
+template <class TA, bool FAST, int MT, int NT, int AUX = 0>
+__device__ __forceinline__ void visible_body(const VisibleArgs& a, int ms, int ns, char* lds)
 {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    if ((int)blockIdx.x < a.n_aux) {  // aux workgroup (dealt first): class conditional of one row, by its first 4 wavefronts
-        if (threadIdx.x >= 256) return;   // (a wavefront that has ended does not take part in the workgroup's barriers)
-        class_row<TA, CM>(a.h, a.U, a.cb, a.py, a.ys, (int)blockIdx.x, a.H, a.C, a.seed, a.offset_y, a.row0,
-                          reinterpret_cast<float*>(lds));
-        return;
-    }
-    constexpr int MT = V_MT, NT = V_NT, NQ = V_NQ;
-    QBM_STAMP(10);
-    asm volatile("" ::"s"(a.h), "s"(a.W), "s"(a.b), "s"(a.p), "s"(a.s), "s"(a.s8), "s"(a.B), "s"(a.V), "s"(a.H), "s"(a.KP),
-                 "s"(a.seed), "s"(a.offset), "s"(a.row0));   // all arguments in one scalar-cache round trip (see k_hidden)
-    const int nM = (a.B + 16 * MT - 1) / (16 * MT), nN = (a.V + 16 * NT - 1) / (16 * NT);
-    int ms, ns;
-    strip_coords(nM, nN, ms, ns, a.n_aux);
+    constexpr int NQ = V_NQ;
     const int m0 = ms * 16 * MT, n0 = ns * 16 * NT;
     const typename KView<TA>::type A{reinterpret_cast<const TA*>(a.h), a.H, a.B};
     const ViewKContig Bv{a.W, a.H, a.V};
-    // Epilogue map: the 64 x 16 strip has 1024 outputs = 2 consecutive visible units for each of the 512 threads.
+    // Epilogue map: the strip (64 x 16, or 32 x 32 in the fused chain) has 1024 outputs = 2 consecutive visible units for
+    // each of the 512 threads.
     // The bias loads are issued behind the first operand transfers (`pre0`) and consumed in the epilogue; the Philox draw
     // runs in `pre`, while the transfers are in flight.
     using SO = StripOut<MT, NT, 2, 64 * NQ>;
@@ -382,7 +401,7 @@ __global__ __launch_bounds__(64 * V_NQ) void k_visible(VisibleArgs a)
         asm volatile("" : "+v"(uu[0]), "+v"(uu[1]));   // not sunk into the epilogue
     };
     QBM_STAMP(11);
-    const auto o = strip_mma<MT, NT, FAST, FAST, 2, NQ, true>(A, Bv, m0, n0, a.H, lds, a.KP, pre0, pre);
+    const auto o = strip_mma<MT, NT, FAST, FAST, 2, NQ, true, AUX>(A, Bv, m0, n0, a.H, lds, a.KP, pre0, pre);
     if (o.valid(0) && i < a.B && k0 < a.V) {
         const float sv[2] = {o.sum[0].x, o.sum[0].y};
         float pv[2], vv[2];
@@ -405,6 +424,194 @@ __global__ __launch_bounds__(64 * V_NQ) void k_visible(VisibleArgs a)
         }
     }
     QBM_STAMP(12);
+}
+
+template <class TA, bool FAST, int CM>
+__global__ __launch_bounds__(64 * V_NQ) void k_visible(VisibleArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    if ((int)blockIdx.x < a.n_aux) {  // aux workgroup (dealt first): class conditional of one row, by its first 4 wavefronts
+        if (threadIdx.x >= 256) return;   // (a wavefront that has ended does not take part in the workgroup's barriers)
+        class_row<TA, CM>(a.h, a.U, a.cb, a.py, a.ys, (int)blockIdx.x, a.H, a.C, a.seed, a.offset_y, a.row0,
+                          reinterpret_cast<float*>(lds));
+        return;
+    }
+    QBM_STAMP(10);
+    asm volatile("" ::"s"(a.h), "s"(a.W), "s"(a.b), "s"(a.p), "s"(a.s), "s"(a.s8), "s"(a.B), "s"(a.V), "s"(a.H), "s"(a.KP),
+                 "s"(a.seed), "s"(a.offset), "s"(a.row0));   // all arguments in one scalar-cache round trip (see k_hidden)
+    const int nM = (a.B + 16 * V_MT - 1) / (16 * V_MT), nN = (a.V + 16 * V_NT - 1) / (16 * V_NT);
+    int ms, ns;
+    strip_coords(nM, nN, ms, ns, a.n_aux);
+    visible_body<TA, FAST, V_MT, V_NT>(a, ms, ns, lds);
+}
+
+// ---------------------------------------------------------------------------------------------
+// A-7 fused: the whole block-Gibbs chain of a CD-k / PCD-k step in ONE launch.
+//
+// The rows of a minibatch are independent along the chain h_0 -> (v_1, y_1) -> h_1 -> ...: only the gradient couples
+// them.  MI355X has 8 XCDs of 32 CUs, each XCD with an L2 of its own that is coherent for its CUs.  So row block g (32
+// rows) is given to the 32 workgroups of ONE XCD -- hidden phase: workgroup j owns the 32 x 16 strip of hidden columns
+// 16 j ..; visible phase: the 32 x 32 strip of visible columns 32 j .. (the workgroups without a strip take the class
+// conditional of the block's rows) -- and the phases of a block are separated by a barrier among those 32 workgroups
+// only: every workgroup publishes its round number in a word of the block's 128-byte flag line with a plain store (it
+// lands in the XCD's L2) and polls the line with ONE L1-bypassing (`sc1`) 32-lane load per try.  Measured
+// (tools/microbench/xcd_barrier.hip): 0.27 us per barrier, against 1.5-1.9 us for a dependent kernel boundary and
+// 3.6 us for a barrier built on an atomic counter.  A state handed from phase to phase is written with plain stores,
+// drained (s_waitcnt vmcnt(0)) before the flag, and read with `sc1` transfers: served by the L2 the producer wrote
+// through, never by the reader's own vector L1 (which no other CU's store refreshes).  W, b, d, U, c are not written
+// during the launch: plain loads, and the second and later phases find them in the XCD's L2.
+//
+// Placement: HIP promises no workgroup -> XCD map.  Workgroups b and b + 8 have shared an XCD in every observation
+// (blocks are dealt round-robin); the kernel takes group = b % 8 on that basis but CHECKS it: every workgroup
+// publishes HW_REG_XCC_ID with its first flag and compares the 32 ids of its group after the first barrier; a
+// mismatch, or a barrier whose bounded spin runs out, sets the status word (sync[512]; read by the host at its next
+// synchronisation point: rbm_ops.check_chain_status) and ends the kernel -- never a hang, never a silently wrong result.
+// The persistent chains are first written in the last visible phase, i.e. after the check.
+// ---------------------------------------------------------------------------------------------
+struct ChainArgs {
+    const float *W, *b, *d, *U, *c;
+    const uint8_t* v0;   // [B,V] data
+    const float* y0;     // [B,C]
+    uint8_t* chain_v;    // persistent chains, or null
+    float* chain_y;
+    float* ph0;          // workspace
+    uint8_t* h;
+    uint8_t* vk;
+    float* yk;
+    float* phk;
+    uint32_t* sync;      // [8][32] round flags | [8][32] XCC ids | status
+    int B, V, H, C, k;
+    int KPh, KPv, ldsCls;
+    uint64_t seed, offset;
+    uint32_t row0;
+    bool vecO;
+};
+
+constexpr int kChainSpin = 1 << 20;   // polls (>= 0.3 us each) before a barrier gives up
+
+__device__ __forceinline__ uint32_t xcc_id()
+{
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xfu;
+}
+
+__device__ __forceinline__ uint32_t load_sc1(const uint32_t* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Barrier among the 32 workgroups of a group (every thread of the workgroup calls it).  false: the spin ran out.
+__device__ __forceinline__ bool group_barrier(uint32_t* flags, int j, uint32_t target, uint32_t* status, uint32_t* s_ok)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's stores have reached the L2
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        if (lane == 0) __hip_atomic_store(&flags[j], target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        bool ok = true;
+        for (int spins = 0;; ++spins) {
+            const uint32_t f = lane < 32 ? load_sc1(&flags[lane]) : target;
+            if (__all((int)(f - target) >= 0)) break;
+            if (spins > kChainSpin) { ok = false; break; }
+        }
+        if (lane == 0) {
+            if (!ok) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *s_ok = ok ? 1u : 0u;
+        }
+    }
+    __syncthreads();
+    return *s_ok != 0u;
+}
+
+template <int CM>
+__global__ __launch_bounds__(512) void k_chain(ChainArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    __shared__ uint32_t s_ok;
+    __shared__ float e_s[2][QBM_MAX_CLASSES + 1];
+    const int g = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+    if (g * 32 >= a.B) return;   // no row block for this group (B < 256): none of its workgroups takes part in anything
+    uint32_t* flags = a.sync + g * 32;
+    uint32_t* ids = a.sync + 256 + g * 32;
+    uint32_t* status = a.sync + 512;
+    uint32_t round = flags[j];   // my last round of the previous launch: the same in every word of the line
+    const uint32_t my_xcc = xcc_id();
+    if (threadIdx.x == 0) ids[j] = my_xcc;
+    bool checked = false;
+
+    const bool pcd = a.chain_v != nullptr;
+    const int nNh = (a.H + 15) / 16, nNv = (a.V + 31) / 32;   // <= 32 each
+    const int n_free = 32 - nNv;                              // workgroups without a visible strip
+    const int n_pre = pcd ? 2 : 1;
+    const int nph = n_pre + 2 * a.k;
+    for (int ph = 0; ph < nph; ++ph) {
+        // ---- decode the phase (the host-side sequence of qbm_rbm_cd_chain)
+        bool hidden = true, sync_first = false;
+        const uint8_t* vin = a.v0;
+        const float* yin = a.y0;
+        float* pout = a.ph0;
+        uint8_t* hout = pcd ? nullptr : a.h;
+        uint8_t* vout = nullptr;
+        float* yout = nullptr;
+        uint64_t off = a.offset;
+        if (ph == 1 && pcd) {          // negative chain starts from the persistent state
+            vin = a.chain_v; yin = a.chain_y; pout = nullptr; hout = a.h;
+        } else if (ph >= n_pre) {
+            const int t = (ph - n_pre) / 2 + 1;
+            const uint64_t o = a.offset + 3ull * (uint64_t)t;
+            vout = (pcd && t == a.k) ? a.chain_v : a.vk;
+            yout = (pcd && t == a.k) ? a.chain_y : a.yk;
+            sync_first = true;
+            if (((ph - n_pre) & 1) == 0) { hidden = false; off = o; }
+            else { vin = vout; yin = yout; pout = a.phk; hout = t < a.k ? a.h : nullptr; off = o; }
+        }
+        if (sync_first) {
+            ++round;
+            if (!group_barrier(flags, j, round, status, &s_ok)) return;
+            if (!checked) {   // all 32 workgroups of the group on one XCD?
+                checked = true;
+                if (threadIdx.x < 64) {
+                    const uint32_t id = threadIdx.x < 32 ? load_sc1(&ids[threadIdx.x]) : my_xcc;
+                    const bool same = __all((int)(id == my_xcc));
+                    if (threadIdx.x == 0) {
+                        if (!same) __hip_atomic_store(status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s_ok = same ? 1u : 0u;
+                    }
+                }
+                __syncthreads();
+                if (s_ok == 0u) return;
+            }
+        }
+        if (hidden) {
+            if (j < nNh) {
+                const HiddenArgs ha{vin, yin, a.W, a.d, a.U, pout, nullptr, hout, a.B, a.V, a.H, a.C, a.KPh, a.seed, off, a.row0,
+                                    false, true, a.ldsCls};
+                hidden_body<uint8_t, 2, 0, CM, kSc1>(ha, g, j, lds);
+            }
+        } else {
+            if (j < nNv) {
+                const VisibleArgs va{a.h, a.W, a.b, nullptr, nullptr, vout, a.B, a.V, a.H, a.KPv, a.seed, off - 2, a.row0, a.vecO,
+                                     a.U, a.c, nullptr, yout, a.C, off - 1, 0};
+                visible_body<uint8_t, true, 2, 2, kSc1>(va, g, j, lds);
+            }
+            // class conditional of the block's 32 rows, two rows at a time per workgroup (teams of 4 wavefronts), on the
+            // workgroups that have no strip -- or, when every workgroup has one, behind the strips
+            const int units = n_free > 0 ? n_free : 32, u = n_free > 0 ? j - nNv : j;
+            if (u >= 0) {
+                const int half = (int)threadIdx.x >> 8, tid = (int)threadIdx.x & 255, teams = 2 * units;
+                for (int r0 = 0; r0 < 32; r0 += teams) {
+                    const int r = r0 + 2 * u + half;
+                    const bool act = r < 32;
+                    const int i = g * 32 + r;
+                    if (act) class_row_energies<uint8_t, CM, true>(a.h, a.U, a.c, i, a.H, a.C, tid, e_s[half]);
+                    __syncthreads();
+                    if (act && tid == 0) class_row_draw<CM>(nullptr, yout, i, a.C, a.seed, off - 1, a.row0, e_s[half]);
+                    __syncthreads();
+                }
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1052,6 +1259,51 @@ int launch_grad(int V, int H, int C, int B, const void* A0, int d0, const float*
 #undef QBM_G
 }
 
+// The fused chain kernel for the shapes it is written for; QBM_OK + *done = false when the classic sequence of launches
+// has to run instead.
+int launch_chain_fused(const qbm_rbm_params* P, const void* v0, int v0_dtype, const float* y0, int B, int k, uint64_t seed,
+                       uint64_t offset, uint32_t row0, uint8_t* chain_v, float* chain_y, const qbm_rbm_cd_workspace* ws,
+                       hipStream_t st, bool* done)
+{
+    *done = false;
+    static const bool enabled = [] {
+        const char* e = getenv("QBM_FUSED_CHAIN");
+        if (e && e[0] == '0') return false;
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+        return cus == 256;   // 8 XCDs x 32 CUs: one workgroup per CU, 32 per XCD
+    }();
+    if (!enabled || !ws->sync || v0_dtype != QBM_U8) return QBM_OK;
+    const int V = P->V, H = P->H, C = P->C;
+    if (B % 32 != 0 || B > 256 || H % 16 != 0 || H > 512 || V % 16 != 0 || V > 1024 || 5 * C + 4 > 64) return QBM_OK;
+    const void* ptrs[] = {v0, y0, P->W, P->b, P->d, P->U, ws->h, ws->vk, ws->yk, chain_v, chain_y};
+    for (const void* q : ptrs)
+        if (q && !aligned16(q)) return QBM_OK;
+    if (!small2g((long)V * H, 4)) return QBM_OK;
+    constexpr int NQ = 8;
+    constexpr int kScratch = NQ * 1024;
+    ChainArgs a{P->W, P->b, P->d, P->U, P->c, (const uint8_t*)v0, y0, chain_v, chain_y, ws->ph0, ws->h, ws->vk, ws->yk, ws->phk,
+                ws->sync, B, V, H, C, k, panel_for_nq<H_MT, H_NT, 1, NQ>(V, kScratch), panel_for_nq<2, 2, 1, NQ>(H, 0), 0, seed,
+                offset, row0, V % 2 == 0};
+    const size_t lds_h = strip_lds_bytes<H_MT, H_NT, 1, NQ>(a.KPh), lds_v = strip_lds_bytes<2, 2, 1, NQ>(a.KPv);
+    a.ldsCls = (int)lds_h;
+    const size_t lds = lds_h + kScratch > lds_v ? lds_h + kScratch : lds_v;
+    // one panel per chain in both phases (the strip kernels' multi-panel loop works here too, this is only the size check)
+    if (lds > 160 * 1024 - 1024) return QBM_OK;
+#define QBM_L(CM)                                                                        \
+    {                                                                                    \
+        if (int rc = set_lds(k_chain<CM>, lds)) return rc;                               \
+        hipLaunchKernelGGL((k_chain<CM>), dim3(256), dim3(512), lds, st, a);             \
+    }
+    QBM_DISPATCH_CM(C, QBM_L);
+#undef QBM_L
+    QBM_CHECK_LAUNCH("k_chain");
+    *done = true;
+    return QBM_OK;
+}
+
+
 }  // namespace
 
 // =================================================================================================
@@ -1200,6 +1452,11 @@ int qbm_rbm_cd_chain(const qbm_rbm_params* P, const void* v0, int v0_dtype, cons
         return fail(QBM_ERR_ARG, "cd_chain: null buffer");
     if ((chain_v == nullptr) != (chain_y == nullptr)) return fail(QBM_ERR_ARG, "cd_chain: chain_v and chain_y go together");
     hipStream_t st = (hipStream_t)stream;
+    {   // one launch for the whole chain where the shape allows it (B <= 256 in blocks of 32 rows, uint8 data)
+        bool done = false;
+        if (int rc = launch_chain_fused(P, v0, v0_dtype, y0, B, k, seed, offset, row0, chain_v, chain_y, ws, st, &done)) return rc;
+        if (done) return QBM_OK;
+    }
     if (chain_v) {
         // positive phase on the data (probabilities only), negative chain from the persistent state
         if (int rc = launch_hidden(P, v0, v0_dtype, y0, B, ws->ph0, nullptr, nullptr, 0, seed, offset, row0, st)) return rc;

@@ -90,9 +90,13 @@ __device__ __forceinline__ uint32_t lds_off(const void* p)
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
 }
 
+// AUX = cache policy of the transfer: 0 = plain, kSc1 = `sc1` (served by the XCD's L2, never by this CU's vector L1: what a
+// workgroup must use for bytes that another CU of its XCD has written during the same launch)
+constexpr int kSc1 = 16;
+template <int AUX = 0>
 __device__ __forceinline__ void blds16(rsrc_t r, unsigned voff, void* lds_piece)
 {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_piece, 16, voff, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_piece, 16, voff, 0, 0, AUX);
 }
 
 // this lane's walk over one 16-wide tile of an operand: byte offset of its 16 B in the first DMA
@@ -391,13 +395,16 @@ __device__ __forceinline__ void vm_wait(int n)
 // ADJACENT in a K-contiguous image: one ds_read_b32 (u8: + v_cvt_f32_ubyte0..3) or one ds_read_b128 (fp32) per tile and
 // piece instead of four byte reads / two ds_read2st64; a row-per-k fp32 image is filled with its rows permuted (a per-lane
 // source address, free) and read as before.
-template <int MT, int NT, bool FAST_A, bool FAST_B, int CPT = 4, int NQ = 4, bool KPERM = false, class AView, class BView,
-          class Pre0 = NoPre, class Pre = NoPre>
+// AUX_A: cache policy of the A operand's transfers (kSc1 inside the fused Gibbs chain, where A is a state another workgroup
+// of the XCD has just written; FAST_A only).
+template <int MT, int NT, bool FAST_A, bool FAST_B, int CPT = 4, int NQ = 4, bool KPERM = false, int AUX_A = 0, class AView,
+          class BView, class Pre0 = NoPre, class Pre = NoPre>
 __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView& A, const BView& Bv, int m0, int n0, int K,
                                                                     char* __restrict__ lds, int KP, Pre0&& pre0 = NoPre{},
                                                                     Pre&& pre = NoPre{}, int stamp0 = 0)
 {
     static_assert(NQ == 4 || NQ == 8, "4 or 8 chains");
+    static_assert(AUX_A == 0 || FAST_A, "a cache policy only applies to LDS-DMA transfers");
     (void)stamp0;   // first stamp slot of this call (diagnostic builds only)
     using TA = typename AView::elem;
     const int qbm_diag = QBM_DIAG_MODE;   // 0 in the product: the diagnostic branches fold away
@@ -619,7 +626,7 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
                 for (int i = 0; i < MT; ++i) {
                     // u8: one instruction covers the 4 pieces (k4 image: of its tile; lin image: a (64/MT)-k slice of
                     // every tile); lanes past the end of the K chain read zeros
-                    blds16(ra, la[i].k < kend ? la[i].voff : kOOB, imgA + (A_TILES ? (qd * MT + i) * 1024 : i * a_tile + qd * 1024));
+                    blds16<AUX_A>(ra, la[i].k < kend ? la[i].voff : kOOB, imgA + (A_TILES ? (qd * MT + i) * 1024 : i * a_tile + qd * 1024));
                     la[i].voff += la[i].step;
                     la[i].k += la[i].kstep;
                 }
@@ -628,7 +635,7 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
                 if constexpr (!A8) {
 #pragma unroll
                     for (int i = 0; i < MT; ++i) {
-                        blds16(ra, la[i].voff, imgA + i * a_tile + pc * 1024);
+                        blds16<AUX_A>(ra, la[i].voff, imgA + i * a_tile + pc * 1024);
                         la[i].voff += la[i].step;
                     }
                 }
@@ -689,7 +696,7 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
                     if constexpr (A_TILES) la = A.template lane0_tiles<MT>(m0, kb, lane, i);
                     else la = view_lane0<KPERM>(A, m0 + 16 * i, kb, lane);
                     for (int g = 0; g < (A8 ? quads : pieces); ++g) {
-                        blds16(ra, (!A8 || la.k < kend) ? la.voff : kOOB, imgA + (A_TILES ? (g * MT + i) * 1024 : i * a_tile + g * 1024));
+                        blds16<AUX_A>(ra, (!A8 || la.k < kend) ? la.voff : kOOB, imgA + (A_TILES ? (g * MT + i) * 1024 : i * a_tile + g * 1024));
                         la.voff += la.step;
                         la.k += la.kstep;
                     }

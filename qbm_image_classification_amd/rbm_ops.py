@@ -212,10 +212,23 @@ class HipRbmOps:
             return (ws[0], ws[1], chain_v, chain_y, ws[4])
         return ws
 
-    def cd_workspace(self, P: ParamSet, B):
+    def cd_workspace(self, P: ParamSet, B, fused=True):
         f = lambda n, dt: torch.empty(B, n, dtype=dt, device=self.device)
+        sync = torch.zeros(_lib.QBM_CD_SYNC_WORDS, dtype=torch.int32, device=self.device) if fused else None
         return (f(P.H, torch.float32), f(P.H, torch.uint8), f(P.V, torch.uint8), f(P.C, torch.float32),
-                f(P.H, torch.float32))  # ph0, h, vk, yk, phk
+                f(P.H, torch.float32), sync)  # ph0, h, vk, yk, phk, state of the fused chain kernel
+
+    @staticmethod
+    def check_chain_status(ws):
+        """Raise if a fused chain launch that used this workspace gave up (include/qbm_hip.h: qbm_rbm_cd_workspace.sync).
+        Synchronises; call it where the host synchronises anyway (end of an epoch, before results are read)."""
+        if len(ws) > 5 and ws[5] is not None:
+            st = int(ws[5][512].item())
+            if st != 0:
+                raise _lib.QbmHipError(
+                    f"fused Gibbs chain kernel gave up (status {st}: " + {1: "a barrier between phases timed out", 2: "the workgroups of "
+                    "a row block were not placed on one XCD"}.get(st, "unknown") + "): the results of that step are invalid; "
+                    "set QBM_FUSED_CHAIN=0 to use one launch per phase")
 
     def update(self, P: ParamSet, G: GradSet, lr, factor, batch_size, sparse, with_gb=True):
         ps, gs = P.struct(), G.struct(with_gb=with_gb)

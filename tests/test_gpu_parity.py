@@ -204,6 +204,46 @@ def test_cd_step_bitwise(ops, oracle, V, H, C, B, k, pcd):
                 assert_bitwise(got, want, f"{nm} after fused update")
 
 
+@pytest.mark.parametrize("V,H,C,B,k,pcd", [(784, 512, 10, 256, 1, False), (784, 512, 10, 256, 3, True), (784, 128, 2, 64, 2, False),
+                                           (1024, 512, 4, 32, 2, True), (64, 32, 12, 96, 1, False), (784, 512, 10, 224, 2, False)])
+def test_fused_chain_kernel_equals_oracle_and_launch_per_phase(ops, oracle, V, H, C, B, k, pcd):
+    """The one-launch Gibbs chain (k_chain: a row block of 32 per XCD, XCD-local flag barriers between the phases, states
+    handed over through the XCD's L2 with sc1 loads) against the oracle AND against the launch-per-phase path (a workspace
+    without the sync buffer), bit for bit, twice in a row on the same workspace (the barrier rounds carry over from launch
+    to launch); its status word stays 0.  Shapes: the benchmark's, PCD, fewer than 8 row blocks, every workgroup holding a
+    visible strip (V = 1024: the class conditional runs behind the strips), the largest class count, a ragged count of blocks."""
+    from qbm_image_classification_amd.rbm_ops import GradSet
+
+    W, b, d, U, c = synth_params(V, H, C, 900 + V + H)
+    v_bin, _, _, labels, y1h = synth_inputs(B, V, H, C, 12)
+    P = P_of(ops, W, b, d, U, c)
+    G = GradSet(V, H, C, ops.device)
+    ws_f, ws_c = ops.cd_workspace(P, B), ops.cd_workspace(P, B, fused=False)
+    assert ws_f[5] is not None and ws_c[5] is None
+    cv0, cy0 = np.roll(v_bin, 1, axis=0).astype(np.uint8), np.roll(y1h, 1, axis=0).copy()
+    chains = {n: ((dev(ops, cv0), dev(ops, cy0)) if pcd else (None, None)) for n in ("f", "c")}
+    ocv, ocy = (cv0.astype(np.float32), cy0.copy()) if pcd else (None, None)
+    v0, y0 = dev(ops, v_bin.astype(np.uint8)), dev(ops, y1h)
+    for rep in range(2):
+        seed, off, row0 = 17, 300 + 50 * rep, 64
+        ph0, vk, yk, phk = oracle.rbm_cd_chain(v_bin, y1h, W, b, d, U, c, k, seed, off, row0, ocv, ocy)
+        outs = {}
+        for n, ws in (("f", ws_f), ("c", ws_c)):
+            outs[n] = ops.cd_step(P, G, v0, y0, k, seed, off, row0, chains[n][0], chains[n][1], False, 0.05, 1.0, float(B), 0.0, ws)
+        ops.check_chain_status(ws_f)
+        for n in ("f", "c"):
+            o = outs[n]
+            assert_bitwise(o[0], ph0, f"p(h0) [{n}, rep {rep}]")
+            assert_bitwise(o[4], phk, f"p(h_k) [{n}, rep {rep}]")
+            if pcd:
+                assert np.array_equal(chains[n][0].cpu().numpy(), ocv.astype(np.uint8)), f"persistent v [{n}, rep {rep}]"
+                assert_bitwise(chains[n][1], ocy, f"persistent y [{n}, rep {rep}]")
+            else:
+                assert np.array_equal(o[2].cpu().numpy(), vk.astype(np.uint8)), f"v_k [{n}, rep {rep}]"
+                assert_bitwise(o[3], yk, f"y_k [{n}, rep {rep}]")
+    assert int(ws_f[5][512].item()) == 0
+
+
 def test_config3_pcd10_full_size_carried_state(ops, oracle):
     """BASELINE.json configs[2] exactly: 784v x 512h, C = 10, CD-10 with persistent chains, batch 256.  Three consecutive
     steps with the chains AND the parameters carried from step to step; every sampled bit, every probability and every
