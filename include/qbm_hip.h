@@ -167,6 +167,11 @@ QBM_API int qbm_rbm_cd_chain(const qbm_rbm_params* P, const void* v0, int v0_dty
                              uint64_t seed, uint64_t offset, uint32_t row0, uint8_t* chain_v, float* chain_y,
                              const qbm_rbm_cd_workspace* ws, void* stream);
 
+/* When qbm_rbm_cd_chain / qbm_rbm_cd_step use the one-launch chain kernel: 0 = never, 1 = where it is faster (from k = 2
+ * on; the default, or the first character of the environment variable QBM_FUSED_CHAIN), 2 = whenever the shape allows.
+ * Process-wide; returns the previous mode (an out-of-range argument only queries). */
+QBM_API int qbm_rbm_fused_chain_mode(int mode);
+
 /* chain + gradient (+ update).  fuse_update == 0: the gradients go to G (all five blocks required; the
  * data-parallel path all-reduces them, then calls qbm_rbm_update).  fuse_update != 0: single-GPU path, every
  * parameter block is updated inside the gradient launch (the non-NULL blocks of G are still written).

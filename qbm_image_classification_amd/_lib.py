@@ -61,6 +61,7 @@ SIGNATURES = {
     "qbm_rbm_sample_visible_class_ex": [_PP, _p, _i, _i, _p, _p, _p, _p, _p, _u64, _u64, _u64, _u32, _p],
     "qbm_f32_to_u8": [_p, _p, C.c_long, _p],
     "qbm_rbm_update": [_PP, _GP, _f, _f, _f, _f, _p],
+    "qbm_rbm_fused_chain_mode": [_i],
     "qbm_rbm_cd_chain": [_PP, _p, _i, _p, _i, _i, _u64, _u64, _u32, _p, _p, C.POINTER(CdWorkspace), _p],
     "qbm_rbm_cd_step": [_PP, _GP, _p, _i, _p, _i, _i, _u64, _u64, _u32, _p, _p, C.POINTER(CdWorkspace), _i, _f, _f,
                         _f, _f, _p],

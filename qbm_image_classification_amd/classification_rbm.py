@@ -260,6 +260,8 @@ class ClassificationRBM:
                 epoch_nll_t += nll.mean().double()
 
             epoch_error, epoch_nll = epoch_error_t.item(), epoch_nll_t.item()
+            if hasattr(self.ops, "check_chain_status"):
+                self.ops.check_chain_status()   # the one-launch Gibbs chain reports a failed placement check here (never silently)
             loss_list.append(epoch_error / len(train_loader))
             nll_list.append(epoch_nll / len(train_loader))
 

@@ -1,6 +1,8 @@
 // rbm_kernels.hip -- ClassificationRBM hot path on gfx950 (MI355X): block-Gibbs conditionals,
 // free-energy evaluation, two-phase (CD-k / discriminative) gradient, parameter update.
 // Reference semantics: src/ClassificationRBM.py (file:line cited per kernel), SURVEY.md 8.A.
+#include <atomic>
+#include <cstdlib>
 #include "strip_mma.hip.h"
 #include "qbm_host.hpp"
 
@@ -314,6 +316,59 @@ __device__ __forceinline__ void class_row_draw(float* __restrict__ p_out, float*
         for (int c = 0; c < C; ++c) y_out[(long)i * C + c] = (c == pick) ? 1.f : 0.f;
 }
 
+// The same conditional by ONE wavefront (the fused chain kernel: a row per wavefront, no LDS, no workgroup barrier):
+// per class the wave tree [T] over j -- lane l chains j = l, l + 64, ... ascending, then the butterfly -- exactly what
+// one of class_row_energies' wavefronts does for its classes; lane 0 normalises and draws like class_row_draw.
+template <class TH, int CM, bool SC1 = false>
+__device__ __forceinline__ void class_row_wave(const void* __restrict__ h, const float* __restrict__ U,
+                                               const float* __restrict__ cb, float* __restrict__ y_out, int i, int H, int C,
+                                               uint64_t seed, uint64_t offset, uint32_t row0, int lane)
+{
+    float e[CM];
+#pragma unroll
+    for (int c = 0; c < CM; ++c) e[c] = 0.f;
+    for (int jb = 0; jb < H; jb += 2 * kWave) {   // two columns per lane and trip: 2 + 2*CM loads in flight
+        float hv[2], uv[2][CM];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int j = jb + t * kWave + lane;
+            const int jj = min(j, H - 1);
+            const float x = ld_state<TH, SC1>(h, (long)i * H + jj);
+            hv[t] = (j < H) ? x : 0.f;
+#pragma unroll
+            for (int c = 0; c < CM; ++c) uv[t][c] = U[(long)min(c, C - 1) * H + jj];
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int c = 0; c < CM; ++c) e[c] = __builtin_fmaf(hv[t], uv[t][c], e[c]);
+    }
+    float ev[CM];
+#pragma unroll
+    for (int c = 0; c < CM; ++c) ev[c] = det_expf(wave_butterfly_sum(e[c]) + cb[min(c, C - 1)]);
+    if (lane != 0) return;
+    float denom = 0.f;
+#pragma unroll
+    for (int c = 0; c < CM; ++c)
+        if (c < C) denom = denom + __builtin_fabsf(ev[c]);
+    if (!(denom > 1e-12f)) denom = 1e-12f;
+    const float u = uniform4(seed, offset, row0 + (uint32_t)i, 0u)[0];
+    float cum = 0.f;
+    int pick = C - 1;
+    bool done = false;
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+        if (c < C) {
+            const float p = ev[c] / denom;
+            cum = cum + p;
+            if (!done && u < cum) { pick = c; done = true; }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CM; ++c)
+        if (c < C) y_out[(long)i * C + c] = (c == pick) ? 1.f : 0.f;
+}
+
 template <class TH, int CM>
 __device__ __forceinline__ void class_row(const void* __restrict__ h, const float* __restrict__ U,
                                           const float* __restrict__ cb, float* __restrict__ p_out,
@@ -529,13 +584,15 @@ __global__ __launch_bounds__(512) void k_chain(ChainArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     __shared__ uint32_t s_ok;
-    __shared__ float e_s[2][QBM_MAX_CLASSES + 1];
     const int g = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
     if (g * 32 >= a.B) return;   // no row block for this group (B < 256): none of its workgroups takes part in anything
     uint32_t* flags = a.sync + g * 32;
     uint32_t* ids = a.sync + 256 + g * 32;
     uint32_t* status = a.sync + 512;
     uint32_t round = flags[j];   // my last round of the previous launch: the same in every word of the line
+    QBM_STAMP(5);
+    int n_bar = 0;   // (diagnostic builds stamp the first two barriers: slots 6/7 and 8/9)
+    (void)n_bar;
     const uint32_t my_xcc = xcc_id();
     if (threadIdx.x == 0) ids[j] = my_xcc;
     bool checked = false;
@@ -568,7 +625,10 @@ __global__ __launch_bounds__(512) void k_chain(ChainArgs a)
         }
         if (sync_first) {
             ++round;
+            if (n_bar < 2) QBM_STAMP(6 + 2 * n_bar);
             if (!group_barrier(flags, j, round, status, &s_ok)) return;
+            if (n_bar < 2) QBM_STAMP(7 + 2 * n_bar);
+            ++n_bar;
             if (!checked) {   // all 32 workgroups of the group on one XCD?
                 checked = true;
                 if (threadIdx.x < 64) {
@@ -595,23 +655,17 @@ __global__ __launch_bounds__(512) void k_chain(ChainArgs a)
                                      a.U, a.c, nullptr, yout, a.C, off - 1, 0};
                 visible_body<uint8_t, true, 2, 2, kSc1>(va, g, j, lds);
             }
-            // class conditional of the block's 32 rows, two rows at a time per workgroup (teams of 4 wavefronts), on the
-            // workgroups that have no strip -- or, when every workgroup has one, behind the strips
-            const int units = n_free > 0 ? n_free : 32, u = n_free > 0 ? j - nNv : j;
-            if (u >= 0) {
-                const int half = (int)threadIdx.x >> 8, tid = (int)threadIdx.x & 255, teams = 2 * units;
-                for (int r0 = 0; r0 < 32; r0 += teams) {
-                    const int r = r0 + 2 * u + half;
-                    const bool act = r < 32;
-                    const int i = g * 32 + r;
-                    if (act) class_row_energies<uint8_t, CM, true>(a.h, a.U, a.c, i, a.H, a.C, tid, e_s[half]);
-                    __syncthreads();
-                    if (act && tid == 0) class_row_draw<CM>(nullptr, yout, i, a.C, a.seed, off - 1, a.row0, e_s[half]);
-                    __syncthreads();
-                }
-            }
+            // class conditional of the block's 32 rows, one row per wavefront, on the workgroups that have no strip -- or,
+            // when every workgroup has one, on the first wavefront of each behind its strip
+            const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+            const int r = n_free > 0 ? (j - nNv) * 8 + wv : (wv == 0 ? j : 32);
+            if (j >= nNv || n_free == 0)
+                for (int rr = r; rr >= 0 && rr < 32; rr += 8 * (n_free > 0 ? n_free : 32))
+                    class_row_wave<uint8_t, CM, true>(a.h, a.U, a.c, yout, g * 32 + rr, a.H, a.C, a.seed, off - 1, a.row0,
+                                                      (int)threadIdx.x & 63);
         }
     }
+    QBM_STAMP(13);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1259,6 +1313,17 @@ int launch_grad(int V, int H, int C, int B, const void* A0, int d0, const float*
 #undef QBM_G
 }
 
+// 0 = never, 1 = where it is faster (default), 2 = whenever the shape allows; initial value from QBM_FUSED_CHAIN
+std::atomic<int>& fused_chain_mode_ref()
+{
+    static std::atomic<int> mode{[] {
+        const char* e = getenv("QBM_FUSED_CHAIN");
+        return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
+    }()};
+    return mode;
+}
+int fused_chain_mode() { return fused_chain_mode_ref().load(); }
+
 // The fused chain kernel for the shapes it is written for; QBM_OK + *done = false when the classic sequence of launches
 // has to run instead.
 int launch_chain_fused(const qbm_rbm_params* P, const void* v0, int v0_dtype, const float* y0, int B, int k, uint64_t seed,
@@ -1266,14 +1331,17 @@ int launch_chain_fused(const qbm_rbm_params* P, const void* v0, int v0_dtype, co
                        hipStream_t st, bool* done)
 {
     *done = false;
-    static const bool enabled = [] {
-        const char* e = getenv("QBM_FUSED_CHAIN");
-        if (e && e[0] == '0') return false;
+    static const bool device_fits = [] {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess) return false;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
         return cus == 256;   // 8 XCDs x 32 CUs: one workgroup per CU, 32 per XCD
     }();
+    const int mode = fused_chain_mode();
+    // mode 1: where it is faster -- from two Gibbs iterations on (CD-1: the first hidden phase of the fused kernel streams all
+    // of W into every XCD, 12.8 MB instead of 1.6, which costs what the two saved launch boundaries gain; measured
+    // 30.0 vs 29.9 us per step; PCD-10: 136 vs 160)
+    const bool enabled = device_fits && (mode == 2 || (mode == 1 && k >= 2));
     if (!enabled || !ws->sync || v0_dtype != QBM_U8) return QBM_OK;
     const int V = P->V, H = P->H, C = P->C;
     if (B % 32 != 0 || B > 256 || H % 16 != 0 || H > 512 || V % 16 != 0 || V > 1024 || 5 * C + 4 > 64) return QBM_OK;
@@ -1310,6 +1378,13 @@ int launch_chain_fused(const qbm_rbm_params* P, const void* v0, int v0_dtype, co
 // C ABI (include/qbm_hip.h)
 // =================================================================================================
 extern "C" {
+
+int qbm_rbm_fused_chain_mode(int mode)
+{
+    if (mode < 0 || mode > 2) return fused_chain_mode();
+    return fused_chain_mode_ref().exchange(mode);
+}
+
 
 int qbm_abi_version(void) { return QBM_ABI_VERSION; }
 const char* qbm_last_error(void) { return g_err; }

@@ -201,8 +201,11 @@ class HipRbmOps:
         B = v0.shape[0]
         if chain_v is not None and chain_v.dtype != torch.uint8:
             raise _lib.QbmHipError("persistent chain state must be uint8")
-        if ws is None:
-            ws = self.cd_workspace(P, B)
+        if ws is None:   # scratch reused from step to step (stream-ordered), like the discriminative step's
+            key = (B, P.V, P.H, P.C)
+            if getattr(self, "_cd_ws", None) is None or self._cd_ws[0] != key:
+                self._cd_ws = (key, self.cd_workspace(P, B))
+            ws = self._cd_ws[1]
         cws = CdWorkspace(*(ptr(t) for t in ws))
         ps, gs = P.struct(), G.struct()
         check(self.lib.qbm_rbm_cd_step(C.byref(ps), C.byref(gs), ptr(v0), vd, ptr(y0), B, k, seed, offset, row0,
@@ -218,10 +221,17 @@ class HipRbmOps:
         return (f(P.H, torch.float32), f(P.H, torch.uint8), f(P.V, torch.uint8), f(P.C, torch.float32),
                 f(P.H, torch.float32), sync)  # ph0, h, vk, yk, phk, state of the fused chain kernel
 
-    @staticmethod
-    def check_chain_status(ws):
-        """Raise if a fused chain launch that used this workspace gave up (include/qbm_hip.h: qbm_rbm_cd_workspace.sync).
-        Synchronises; call it where the host synchronises anyway (end of an epoch, before results are read)."""
+    def fused_chain_mode(self, mode=-1):
+        """0 = never use the one-launch chain kernel, 1 = where it is faster (k >= 2; default), 2 = whenever the shape allows;
+        -> previous mode (no argument: query).  Process-wide (include/qbm_hip.h: qbm_rbm_fused_chain_mode)."""
+        return int(self.lib.qbm_rbm_fused_chain_mode(int(mode)))
+
+    def check_chain_status(self, ws=None):
+        """Raise if a fused chain launch that used this workspace (default: the one cd_step keeps) gave up
+        (include/qbm_hip.h: qbm_rbm_cd_workspace.sync).  Synchronises; call it where the host synchronises anyway (end of an
+        epoch, before results are read)."""
+        if ws is None:
+            ws = self._cd_ws[1] if getattr(self, "_cd_ws", None) is not None else ()
         if len(ws) > 5 and ws[5] is not None:
             st = int(ws[5][512].item())
             if st != 0:

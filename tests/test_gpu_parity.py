@@ -224,6 +224,15 @@ def test_fused_chain_kernel_equals_oracle_and_launch_per_phase(ops, oracle, V, H
     chains = {n: ((dev(ops, cv0), dev(ops, cy0)) if pcd else (None, None)) for n in ("f", "c")}
     ocv, ocy = (cv0.astype(np.float32), cy0.copy()) if pcd else (None, None)
     v0, y0 = dev(ops, v_bin.astype(np.uint8)), dev(ops, y1h)
+    prev = ops.fused_chain_mode(2)      # the fused kernel for every shape it takes (default: from k = 2 on)
+    try:
+        _fused_chain_rounds(ops, oracle, P, G, ws_f, ws_c, chains, ocv, ocy, v_bin, y1h, v0, y0, W, b, d, U, c, k, pcd, B)
+    finally:
+        ops.fused_chain_mode(prev)
+    assert int(ws_f[5][512].item()) == 0
+
+
+def _fused_chain_rounds(ops, oracle, P, G, ws_f, ws_c, chains, ocv, ocy, v_bin, y1h, v0, y0, W, b, d, U, c, k, pcd, B):
     for rep in range(2):
         seed, off, row0 = 17, 300 + 50 * rep, 64
         ph0, vk, yk, phk = oracle.rbm_cd_chain(v_bin, y1h, W, b, d, U, c, k, seed, off, row0, ocv, ocy)
@@ -241,7 +250,6 @@ def test_fused_chain_kernel_equals_oracle_and_launch_per_phase(ops, oracle, V, H
             else:
                 assert np.array_equal(o[2].cpu().numpy(), vk.astype(np.uint8)), f"v_k [{n}, rep {rep}]"
                 assert_bitwise(o[3], yk, f"y_k [{n}, rep {rep}]")
-    assert int(ws_f[5][512].item()) == 0
 
 
 def test_config3_pcd10_full_size_carried_state(ops, oracle):

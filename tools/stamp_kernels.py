@@ -53,6 +53,7 @@ def main():
     for name, argtypes in _lib.SIGNATURES.items():
         if name.startswith("qbm_rbm_"):       # this library holds the rbm_kernels.hip translation unit only
             getattr(lib, name).argtypes = argtypes
+            getattr(lib, name).restype = C.c_int
     lib.qbm_diag_read_stamps.argtypes = [C.c_void_p, C.c_int]
     V, H, NC, B = 784, 512, 10, int(os.environ.get("QBM_STAMP_B", 256))
     dev = torch.device("cuda:0")
@@ -75,6 +76,10 @@ def main():
         "k_grad": (lambda: lib.qbm_rbm_two_phase_grad(V, H, NC, B, p(v0), 1, p(y0), p(ph0), p(vk), 1, p(yk), p(phk), C.byref(G), p(Wsc), None,
                                                      0.05, 1.0, float(B), 0.0, None), 238 * 8),
     }
+    sync = torch.zeros(_lib.QBM_CD_SYNC_WORDS, dtype=torch.int32, device=dev)
+    cws = _lib.CdWorkspace(p(ph0), p(h), p(vk), p(yk), p(phk), p(sync))
+    lib.qbm_rbm_fused_chain_mode(2)     # the fused kernel also for CD-1 (default: from k = 2 on)
+    kernels["k_chain"] = (lambda: lib.qbm_rbm_cd_chain(C.byref(P), p(v0), 1, p(y0), B, 1, 42, 0, 0, None, None, C.byref(cws), None), 256 * 8)
     for f, _ in kernels.values():    # warm: code objects loaded, caches in their steady state
         for _ in range(3):
             assert f() == 0
@@ -89,6 +94,12 @@ def main():
                       (3, 4, "phase 0: combine"), (4, 12, "phase 0 group: swap + epilogue"), (5, 6, "phase 1: LDS-DMA issued"),
                       (6, 7, "phase 1: quad landed"), (7, 8, "phase 1: MFMA loop"), (8, 9, "phase 1: combine"),
                       (9, 12, "phase 1 group: swap + epilogue"), (10, 12, "WAVE LIFETIME")]}
+    # fused chain (CD-1): slots 5 entry, 6/7 before/after the first barrier, 8/9 the second, 13 exit; the phases' own stamps
+    # (0..4, 11, 12) are those of the LAST hidden phase
+    seq["k_chain"] = [(5, 6, "hidden phase 0 (cold)"), (6, 7, "barrier 1 (incl. waiting for the slowest workgroup)"),
+                      (7, 8, "visible phase + class rows"), (8, 9, "barrier 2"), (9, 13, "hidden phase 1"),
+                      (11, 0, "  last hidden phase: to strip_mma entry"), (0, 1, "  requests issued"), (1, 2, "  first quad landed"),
+                      (2, 3, "  MFMA loop"), (3, 4, "  combine"), (4, 12, "  epilogue"), (5, 13, "WAVE LIFETIME")]
     for name, (f, _) in kernels.items():     # back-to-back launch time of the stamped build (stamps cost a few %)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -107,7 +118,7 @@ def main():
             lib.qbm_diag_read_stamps(buf.ctypes.data_as(C.c_void_p), n_waves)
             res.append(buf)
         st = res[-1].astype(np.int64)
-        ok = (st[:, 10] != 0) & (st[:, 12] != 0) & (st[:, 11] != 0)     # strip workgroups that ran to the end
+        ok = ((st[:, 10] != 0) & (st[:, 12] != 0) & (st[:, 11] != 0)) if name != "k_chain" else (st[:, 13] != 0)     # workgroups that ran to the end
         st = st[ok]
         print(f"== {name}: {ok.sum()} stamped waves (s_memtime is per XCD: only differences inside one wave are meaningful)")
         for a, bb, what in seq[name]:
