@@ -96,7 +96,8 @@ constexpr int H_NQ = 8;
 // AUX: cache policy of the loads of v and y (kSc1 inside the fused chain kernel: another workgroup of the XCD wrote them
 // during this launch; FASTK == 2 only).  The body of strip (ms, ns); the caller is a 512-thread workgroup.
 template <class TA, int FASTK, int MODE, int CM, int AUX = 0>
-__device__ __forceinline__ void hidden_body(const HiddenArgs& a, int ms, int ns, char* lds)
+__device__ __forceinline__ void hidden_body(const HiddenArgs& a, int ms, int ns, char* lds, char* ldsB = nullptr,
+                                            bool b_resident = false)
 {
     constexpr bool FAST = FASTK >= 1;
     static_assert(AUX == 0 || FASTK == 2, "cache policies apply to the all-DMA variant");
@@ -207,7 +208,7 @@ __device__ __forceinline__ void hidden_body(const HiddenArgs& a, int ms, int ns,
         }
     };
     QBM_STAMP(11);
-    const auto o = strip_mma<MT, NT, FAST, FAST, 1, NQ, true, AUX>(A, Bv, m0, n0, a.V, lds, a.KP, pre0, pre);
+    const auto o = strip_mma<MT, NT, FAST, FAST, 1, NQ, true, AUX>(A, Bv, m0, n0, a.V, lds, a.KP, pre0, pre, 0, ldsB, b_resident);
     if (o.valid(0) && row < a.B && j0 < a.H) {
         float x = o.sum[0].x + dv, pv, hv = 0.f;
         if (MODE == 0) {
@@ -537,6 +538,7 @@ struct ChainArgs {
     uint32_t* sync;      // [8][32] round flags | [8][32] XCC ids | status
     int B, V, H, C, k;
     int KPh, KPv, ldsCls;
+    int ldsT;            // the W panel of the hidden phases stays in LDS bytes [0, ldsT); everything else is staged behind it
     uint64_t seed, offset;
     uint32_t row0;
     bool vecO;
@@ -596,6 +598,7 @@ __global__ __launch_bounds__(512) void k_chain(ChainArgs a)
     const uint32_t my_xcc = xcc_id();
     if (threadIdx.x == 0) ids[j] = my_xcc;
     bool checked = false;
+    bool w_resident = false;   // this workgroup's 16 columns of W are in LDS: staged by its first hidden phase, kept for the others
 
     const bool pcd = a.chain_v != nullptr;
     const int nNh = (a.H + 15) / 16, nNv = (a.V + 31) / 32;   // <= 32 each
@@ -647,13 +650,14 @@ __global__ __launch_bounds__(512) void k_chain(ChainArgs a)
             if (j < nNh) {
                 const HiddenArgs ha{vin, yin, a.W, a.d, a.U, pout, nullptr, hout, a.B, a.V, a.H, a.C, a.KPh, a.seed, off, a.row0,
                                     false, true, a.ldsCls};
-                hidden_body<uint8_t, 2, 0, CM, kSc1>(ha, g, j, lds);
+                hidden_body<uint8_t, 2, 0, CM, kSc1>(ha, g, j, lds + a.ldsT, lds, w_resident);
+                w_resident = true;
             }
         } else {
             if (j < nNv) {
                 const VisibleArgs va{a.h, a.W, a.b, nullptr, nullptr, vout, a.B, a.V, a.H, a.KPv, a.seed, off - 2, a.row0, a.vecO,
                                      a.U, a.c, nullptr, yout, a.C, off - 1, 0};
-                visible_body<uint8_t, true, 2, 2, kSc1>(va, g, j, lds);
+                visible_body<uint8_t, true, 2, 2, kSc1>(va, g, j, lds + a.ldsT);
             }
             // class conditional of the block's 32 rows, one row per wavefront, on the workgroups that have no strip -- or,
             // when every workgroup has one, on the first wavefront of each behind its strip
@@ -1352,13 +1356,16 @@ int launch_chain_fused(const qbm_rbm_params* P, const void* v0, int v0_dtype, co
     constexpr int NQ = 8;
     constexpr int kScratch = NQ * 1024;
     ChainArgs a{P->W, P->b, P->d, P->U, P->c, (const uint8_t*)v0, y0, chain_v, chain_y, ws->ph0, ws->h, ws->vk, ws->yk, ws->phk,
-                ws->sync, B, V, H, C, k, panel_for_nq<H_MT, H_NT, 1, NQ>(V, kScratch), panel_for_nq<2, 2, 1, NQ>(H, 0), 0, seed,
+                ws->sync, B, V, H, C, k, (chain_len(V, NQ) + 63) / 64 * 64, panel_for_nq<2, 2, 1, NQ>(H, 0), 0, 0, seed,
                 offset, row0, V % 2 == 0};
-    const size_t lds_h = strip_lds_bytes<H_MT, H_NT, 1, NQ>(a.KPh), lds_v = strip_lds_bytes<2, 2, 1, NQ>(a.KPv);
-    a.ldsCls = (int)lds_h;
-    const size_t lds = lds_h + kScratch > lds_v ? lds_h + kScratch : lds_v;
-    // one panel per chain in both phases (the strip kernels' multi-panel loop works here too, this is only the size check)
-    if (lds > 160 * 1024 - 1024) return QBM_OK;
+    // LDS: [W panel of the hidden phases, resident | transient: A tiles + epilogue scratch of a hidden phase, or the whole
+    // staging of a visible phase].  One panel per chain in the hidden phases (the resident image IS the whole chain).
+    if (a.KPh < chain_len(V, NQ)) return QBM_OK;
+    a.ldsT = NQ * strip_wave_bytes_b<H_NT>(a.KPh);
+    const size_t lds_ha = (size_t)NQ * strip_wave_bytes_a<H_MT, H_NT, 1>(a.KPh), lds_v = strip_lds_bytes<2, 2, 1, NQ>(a.KPv);
+    a.ldsCls = (int)lds_ha;
+    const size_t lds = a.ldsT + (lds_ha + kScratch > lds_v ? lds_ha + kScratch : lds_v);
+    if (lds > 160 * 1024) return QBM_OK;
 #define QBM_L(CM)                                                                        \
     {                                                                                    \
         if (int rc = set_lds(k_chain<CM>, lds)) return rc;                               \

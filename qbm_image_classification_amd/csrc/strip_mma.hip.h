@@ -318,6 +318,16 @@ __host__ __device__ constexpr int strip_wave_bytes(int KP)
 }
 template <int MT, int NT, int ASZ, int NQ = 4>
 __host__ __device__ constexpr int strip_lds_bytes(int KP) { return NQ * strip_wave_bytes<MT, NT, ASZ>(KP); }
+// the same with the B images in a region of their own (strip_mma's `ldsB`): per wave the A tiles / the partial strip here,
+// NT * 16 * KP * 4 bytes of B images there
+template <int MT, int NT, int ASZ>
+__host__ __device__ constexpr int strip_wave_bytes_a(int KP)
+{
+    const int stage = MT * 16 * KP * ASZ, red = 16 * MT * (16 * NT + 4) * 4;
+    return stage > red ? stage : red;
+}
+template <int NT>
+__host__ __device__ constexpr int strip_wave_bytes_b(int KP) { return NT * 16 * KP * 4; }
 
 // largest panel (multiple of 64) that fits 160 KiB (less `reserve` bytes) with NQ waves and keeps the DMA count under
 // vm_wait's range
@@ -401,8 +411,12 @@ template <int MT, int NT, bool FAST_A, bool FAST_B, int CPT = 4, int NQ = 4, boo
           class BView, class Pre0 = NoPre, class Pre = NoPre>
 __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView& A, const BView& Bv, int m0, int n0, int K,
                                                                     char* __restrict__ lds, int KP, Pre0&& pre0 = NoPre{},
-                                                                    Pre&& pre = NoPre{}, int stamp0 = 0)
+                                                                    Pre&& pre = NoPre{}, int stamp0 = 0,
+                                                                    char* __restrict__ ldsB = nullptr, bool b_resident = false)
 {
+    // ldsB != nullptr: the B images live in a region of their own (NQ * strip_wave_bytes_b<NT>(KP) bytes) instead of behind
+    // each wave's A tiles; b_resident: they are already there (the caller ran this very contraction's B operand through
+    // this function before, with one panel per chain, and nothing has overwritten the region): no B transfers are issued.
     static_assert(NQ == 4 || NQ == 8, "4 or 8 chains");
     static_assert(AUX_A == 0 || FAST_A, "a cache policy only applies to LDS-DMA transfers");
     (void)stamp0;   // first stamp slot of this call (diagnostic builds only)
@@ -419,10 +433,11 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
     const int Kq = chain_len(K, NQ);
     const int kq0 = q * Kq;
     const int kend = min(K, kq0 + Kq);
-    const int wave_bytes = strip_wave_bytes<MT, NT, ASZ>(KP);
+    const int wave_bytes = ldsB ? strip_wave_bytes_a<MT, NT, ASZ>(KP) : strip_wave_bytes<MT, NT, ASZ>(KP);
     char* img = lds + (size_t)q * wave_bytes;
     char* imgA = img;                              // MT tiles of 16*KP*ASZ bytes
-    char* imgB = img + (size_t)MT * 16 * KP * ASZ;  // NT tiles of 16*KP*4 bytes
+    char* imgB = ldsB ? ldsB + (size_t)q * strip_wave_bytes_b<NT>(KP) : img + (size_t)MT * 16 * KP * ASZ;  // NT tiles of 16*KP*4 bytes
+    const int nt_dma = b_resident ? 0 : NT;        // B tiles transferred per piece
     // u8 "lin" A image: the MT row tiles interleaved per k (see the header); every other image: one region per tile
     constexpr bool A_TILES = A8 && !A_K4;
     const int a_tile = A_TILES ? 16 : 16 * KP * ASZ, b_tile = 16 * KP * 4;
@@ -618,7 +633,7 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
             for (int t = 0; t < NT; ++t) lb[t] = view_lane0<KPERM>(Bv, n0 + 16 * t, kb, lane);
         };
         auto quad_pieces = [&](int qd) { return min(4, pieces - 4 * qd); };
-        auto quad_dmas = [&](int qd) { return qd < quads ? (A8 ? MT : MT * quad_pieces(qd)) + NT * quad_pieces(qd) : 0; };
+        auto quad_dmas = [&](int qd) { return qd < quads ? (A8 ? MT : MT * quad_pieces(qd)) + nt_dma * quad_pieces(qd) : 0; };
         auto issue_quad = [&](int qd) {
             const int np = quad_pieces(qd);
             if constexpr (A8) {
@@ -639,10 +654,12 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
                         la[i].voff += la[i].step;
                     }
                 }
+                if (!b_resident) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    blds16(rb, lb[t].voff, imgB + t * b_tile + pc * 1024);
-                    lb[t].voff += lb[t].step;
+                    for (int t = 0; t < NT; ++t) {
+                        blds16(rb, lb[t].voff, imgB + t * b_tile + pc * 1024);
+                        lb[t].voff += lb[t].step;
+                    }
                 }
             }
         };
