@@ -285,7 +285,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "ClassificationRBM 784v x 512h, C=10, CD-1, batch 256 per GPU (BASELINE.json configs[3] shape; "
                                    "global batch 256*N, RCCL all-reduce of the flat gradient per step when N>1)",
-                       "batch_per_gpu": B, "cd_k": K_CD, "warmup_steps_run": warm_steps, "launch": (f"hipGraph x{graphs[1]} steps" if graphs else "eager") + (f" ({graph_note})" if graph_note else ""),
+                       "batch_per_gpu": B, "cd_k": K_CD, "warmup_steps_run": warm_steps,
+                       "draws": "a replayed graph repeats the draw ids and minibatches it captured (same work per step)" if graphs else "fresh draw ids per step", "launch": (f"hipGraph x{graphs[1]} steps" if graphs else "eager") + (f" ({graph_note})" if graph_note else ""),
                        "parallelism": f"dp{world}" + (" (forced data-parallel path)" if args.force_dp and world == 1 else "")},
             "visible_unit_updates_per_sec": round(value * V, 1),
             "roofline": roofline, "cpu_baseline": cpu,
