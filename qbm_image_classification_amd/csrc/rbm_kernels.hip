@@ -1184,6 +1184,13 @@ int launch_hidden_t(const qbm_rbm_params* P, const void* v, const float* y, int 
     const bool fast = (P->V % 16 == 0) && aligned16(v) && (P->H % 4 == 0) && aligned16(P->W) &&
                       small2g((long)B * P->V, ASZ) && small2g((long)P->V * P->H, 4);
     const int nM = (B + 16 * MT - 1) / (16 * MT), nN = (P->H + 16 * NT - 1) / (16 * NT);
+    // More strips than CUs (B > 256 at H = 512): panels of 64 k, i.e. 56 KB of LDS instead of 104 KB, so that TWO workgroups
+    // share a CU and one's transfers run under the other's MFMAs (784x512, uint8 states: B = 512 / 1024 / 2048 / 4096:
+    // 48 / 83 / 141 / 262 us per CD-1 step against 51 / 92 / 161 / 306 with whole-chain panels; at B = 256, one workgroup
+    // per CU either way, the whole-chain panel is 1-2 % faster).  Measured and dropped for the same sizes: workgroups that
+    // keep their W panel in LDS and walk the row strips (50 / 86 / 150 / 281 us; for k_visible, whose 48 KB already allow
+    // three workgroups per CU, slower than the plain grid).
+    if (ASZ == 1 && fast && nM * nN > 256 && a.KP > 64) a.KP = 64;
     size_t lds = strip_lds_bytes<MT, NT, ASZ, NQ>(a.KP);
     // epilogue operands by LDS-DMA: ONE transfer instruction holds the U tile (4*C chunks of 16 B), the 4 y rows of a
     // wavefront (C chunks) and the bias tile (4 chunks); whole, 16-byte aligned chunks only

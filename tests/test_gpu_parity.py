@@ -111,6 +111,31 @@ def test_conditionals_bitwise(ops, oracle, V, H, C, B):
     assert_bitwise(ys, so, "y sample riding along")
 
 
+@pytest.mark.parametrize("V,H,C,B", [(784, 512, 10, 544), (784, 512, 10, 2048), (256, 64, 2, 1200), (784, 512, 0, 1024)])
+def test_large_batch_conditionals_bitwise(ops, oracle, V, H, C, B):
+    """Minibatches with more strips than CUs (B > 256 at H = 512): sample_hidden switches to panels of 64 k (two workgroups
+    per CU, two panels per chain at V = 784); uint8 states; C = 0 here: without the class term.  Same bits as the oracle."""
+    with_y = C > 0
+    C = C or 2
+    W, b, d, U, c = synth_params(V, H, C, 700 + V + H)
+    v_bin, _, h_bin, labels, y1h = synth_inputs(B, V, H, C, 17)
+    P = P_of(ops, W, b, d, U, c)
+    seed, off, row0 = 31, 9, 4096
+    ph_o, sh_o = oracle.rbm_sample_hidden(v_bin, y1h if with_y else None, W, d, U, seed, off, row0)
+    p8, sf, s8 = ops.sample_hidden_ex(P, dev(ops, v_bin.astype(np.uint8)), dev(ops, y1h) if with_y else None, seed, off, row0,
+                                      True, True, True)
+    assert_bitwise(p8, ph_o, "p(h|v u8,y)")
+    assert np.array_equal(s8.cpu().numpy(), sh_o.astype(np.uint8))
+    pv_o, sv_o = oracle.rbm_sample_visible(h_bin, W, b, seed, off + 1, row0)
+    po, so = oracle.rbm_sample_class(h_bin, U, c, seed, off + 2, row0)
+    pv, vf, v8, py, ys = ops.sample_visible_class(P, dev(ops, h_bin.astype(np.uint8)), seed, off + 1, off + 2, row0,
+                                                  True, True, True, True, True)
+    assert_bitwise(pv, pv_o, "p(v|h u8)")
+    assert np.array_equal(v8.cpu().numpy(), sv_o.astype(np.uint8))
+    assert_bitwise(py, po, "p(y|h u8)")
+    assert_bitwise(ys, so, "y sample")
+
+
 @pytest.mark.parametrize("V,H,C,B", SHAPES)
 def test_free_energy_bitwise(ops, oracle, V, H, C, B):
     W, b, d, U, c = synth_params(V, H, C, 200 + V + H)
