@@ -82,7 +82,6 @@ struct HiddenArgs {
     int KP;
     uint64_t seed, offset;
     uint32_t row0;
-    bool vecO;
     bool epiDma;   // the epilogue operands (bias tile, U tile, y rows) of a wavefront come by LDS-DMA transfers
     int ldsCls;    // byte offset of the per-wavefront scratch of those transfers (2 KiB each) in the dynamic LDS
 };
@@ -649,7 +648,7 @@ __global__ __launch_bounds__(512) void k_chain(ChainArgs a)
         if (hidden) {
             if (j < nNh) {
                 const HiddenArgs ha{vin, yin, a.W, a.d, a.U, pout, nullptr, hout, a.B, a.V, a.H, a.C, a.KPh, a.seed, off, a.row0,
-                                    false, true, a.ldsCls};
+                                    true, a.ldsCls};
                 hidden_body<uint8_t, 2, 0, CM, kSc1>(ha, g, j, lds + a.ldsT, lds, w_resident);
                 w_resident = true;
             }
@@ -1179,7 +1178,7 @@ int launch_hidden_t(const qbm_rbm_params* P, const void* v, const float* y, int 
     constexpr int ASZ = (int)sizeof(TA), MT = H_MT, NT = H_NT, NQ = H_NQ;
     constexpr int kScratch = NQ * 1024;   // one 1 KiB transfer slot per wavefront for the epilogue operands
     HiddenArgs a{v, y, P->W, P->d, P->U, p, s, s8, B, P->V, P->H, P->C, panel_for_nq<MT, NT, ASZ, NQ>(P->V, kScratch), seed,
-                 offset, row0, false, false, 0};
+                 offset, row0, false, 0};
     // LDS-DMA path: whole 16-k pieces, 16-byte aligned units, descriptors below 2 GiB
     const bool fast = (P->V % 16 == 0) && aligned16(v) && (P->H % 4 == 0) && aligned16(P->W) &&
                       small2g((long)B * P->V, ASZ) && small2g((long)P->V * P->H, 4);
