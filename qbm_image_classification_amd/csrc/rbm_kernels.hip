@@ -37,7 +37,10 @@ namespace {
 #define QBM_H_NT 1
 #endif
 constexpr int H_MT = QBM_H_MT, H_NT = QBM_H_NT;
-constexpr int V_MT = 4, V_NT = 1;
+#ifndef QBM_V_MT
+#define QBM_V_MT 4
+#endif
+constexpr int V_MT = QBM_V_MT, V_NT = 1;
 constexpr int G_MT = 4, G_NT = 2;
 
 // class-count buckets for the kernels that keep one register (or one float4) per class
