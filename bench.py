@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--graph", type=int, default=8, help="steps captured per hipGraph (0 = eager launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dp-graph", type=int, default=0, help="with several ranks: capture the data-parallel step (RCCL all-reduce included) in hipGraphs")
     ap.add_argument("--force-dp", action="store_true",
                     help="run the data-parallel code path (gradient all-reduce + separate update) even with one rank")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -130,6 +131,12 @@ def main():
 
     graphs = None
     graph_note = None
+    if dp and world > 1 and not args.dp_graph:
+        # Several ranks: eager launches by default.  The captured data-parallel step has only ever run on ONE rank (no
+        # multi-GPU box is available to the build); a collective captured inconsistently across ranks would not raise but
+        # hang, and with an all-reduce in every step the host keeps up with the device anyway.  --dp-graph 1 captures.
+        args.graph = 0
+        graph_note = "data-parallel step on several ranks: eager launches (--dp-graph 1 captures RCCL in the graph)"
     if args.graph > 0 and dp:
         # data-parallel step (gradient materialised, RCCL all-reduce, update) captured as well: RCCL collectives are
         # capturable; if this build of torch / RCCL refuses, the bench falls back to eager launches and says so
