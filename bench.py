@@ -235,17 +235,14 @@ def main():
 
     # warm-up: at least W steps, through the launch path that is timed (whole graph replays when steps are captured)
     warm_steps = args.warmup if graphs is None else -(-args.warmup // graphs[1]) * graphs[1]
+    # (nothing host-side between the per-kernel timing above, the warm-up and the timed region: a 30 ms pause there -- a
+    # gc.collect() was tried -- lets the device clock down and costs a 20-step region 1.1 us per step)
     run(warm_steps)
-    import gc
-
-    gc.collect()
-    gc.disable()      # no collector pause inside a timed region that may be only a few hundred microseconds long
     barrier()
     t0 = time.perf_counter()
     run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    gc.enable()
     if dp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
