@@ -219,8 +219,11 @@ __global__ __launch_bounds__(64 * kGibbsLdsWaves) void k_qubo_gibbs_lds(const fl
     JTri<NF> jr{tri, n, {}, {}};
     jr.setup(lane);
     const int waves = (int)blockDim.x >> 6;
-    const int total = gridDim.x * waves;
-    for (int ch = blockIdx.x * waves + w; ch < nchains; ch += total)
+    // chains are dealt to the WORKGROUPS round-robin (workgroup b: chains b, b + grid, b + 2 grid, ...) and inside a workgroup
+    // to its wavefronts: every CU gets the same number of chains +-1.  (Dealt to the wavefronts of the whole grid instead,
+    // 7300 chains on 4096 wavefronts leave the last 56 workgroups without a second chain: a fifth of the CUs idle for half
+    // of the launch.)  Draws depend on the chain index only, not on who runs it.
+    for (int ch = (int)blockIdx.x + (int)gridDim.x * w; ch < nchains; ch += (int)gridDim.x * waves)
         gibbs_chain<NF>(lin, jr, ch, R, n, sweeps, beta0, beta1, beta_dev, seed, offset, chain0, states, lane);
 }
 
