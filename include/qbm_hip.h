@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define QBM_ABI_VERSION 9
+#define QBM_ABI_VERSION 10
 #define QBM_MAX_CLASSES 15 /* class rows + the bias row share one 16-row gradient tile */
 #define QBM_MAX_QUBO_VARS 1024
 
@@ -198,6 +198,13 @@ QBM_API int qbm_rbm_disc_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, c
                               const int32_t* labels, int B, float* p_y, float* neg_free_energy,
                               const qbm_rbm_disc_workspace* ws, int apply_update, int fuse_update, float lr,
                               float factor, float batch_size, float sparse_constant, void* stream);
+
+/* The same with x[B,V] as fp32 or as uint8 {0,1} (x_dtype): binary inputs as bytes take the uint8 kernels (a quarter of the
+ * operand bytes; the two phases of the gradient run side by side).  Same values as the fp32 input 0.0 / 1.0. */
+QBM_API int qbm_rbm_disc_step_ex(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void* x, int x_dtype,
+                                 const int32_t* labels, int B, float* p_y, float* neg_free_energy,
+                                 const qbm_rbm_disc_workspace* ws, int apply_update, int fuse_update, float lr,
+                                 float factor, float batch_size, float sparse_constant, void* stream);
 
 /* ---- device-resident dataset pipeline ----------------------------------
  * The outputs of src/data_loader.py (get_mnist :23-73, get_medmnist :115-169, preprocess_images :240-277) are moved

@@ -8,7 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libqbm_hip.so")
 
-QBM_ABI_VERSION = 9
+QBM_ABI_VERSION = 10
 QBM_MAX_CLASSES = 15
 QBM_F32, QBM_U8 = 0, 1
 
@@ -66,6 +66,7 @@ SIGNATURES = {
     "qbm_rbm_cd_step": [_PP, _GP, _p, _i, _p, _i, _i, _u64, _u64, _u32, _p, _p, C.POINTER(CdWorkspace), _i, _f, _f,
                         _f, _f, _p],
     "qbm_rbm_disc_step": [_PP, _GP, _p, _p, _i, _p, _p, C.POINTER(DiscWorkspace), _i, _i, _f, _f, _f, _f, _p],
+    "qbm_rbm_disc_step_ex": [_PP, _GP, _p, _i, _p, _i, _p, _p, C.POINTER(DiscWorkspace), _i, _i, _f, _f, _f, _f, _p],
     "qbm_data_binarise": [_p, C.c_long, _f, _p, _p],
     "qbm_data_pack_bits": [_p, _i, _i, _p, _p],
     "qbm_data_shuffle_keys": [_u64, _u64, _i, _p, _p],

@@ -1593,7 +1593,16 @@ int qbm_rbm_disc_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const flo
                       float* p_y, float* neg_free_energy, const qbm_rbm_disc_workspace* ws, int apply_update,
                       int fuse_update, float lr, float factor, float batch_size, float sparse_constant, void* stream)
 {
+    return qbm_rbm_disc_step_ex(P, G, x, QBM_F32, labels, B, p_y, neg_free_energy, ws, apply_update, fuse_update, lr, factor,
+                                batch_size, sparse_constant, stream);
+}
+
+int qbm_rbm_disc_step_ex(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void* x, int x_dtype, const int32_t* labels,
+                         int B, float* p_y, float* neg_free_energy, const qbm_rbm_disc_workspace* ws, int apply_update,
+                         int fuse_update, float lr, float factor, float batch_size, float sparse_constant, void* stream)
+{
     if (int rc = check_params(P)) return rc;
+    if (int rc = check_dtype(x_dtype)) return rc;
     if (B < 0) return fail(QBM_ERR_ARG, "B < 0");
     if (B == 0) return zero_grads(P, G, (hipStream_t)stream);
     if (!G || !G->gd || !G->gU || !G->gc) return fail(QBM_ERR_ARG, "disc_step: gd, gU, gc are required");
@@ -1605,7 +1614,7 @@ int qbm_rbm_disc_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const flo
     hipStream_t st = (hipStream_t)stream;
     // 1. pre = d + x.W   2. -F, p(y|x), pos / neg / onehot per row   3. class part: usub = sum_i o p, gc (+ c, b update)
     // 4. gW, gU, gd from the two "phases" (x, onehot, pos) and (x, -, neg); every remaining update fused
-    if (int rc = launch_hidden(P, x, QBM_F32, nullptr, B, ws->pre, nullptr, nullptr, 1, 0, 0, 0, st)) return rc;
+    if (int rc = launch_hidden(P, x, x_dtype, nullptr, B, ws->pre, nullptr, nullptr, 1, 0, 0, 0, st)) return rc;
 #define QBM_L(CM)                                                                                               \
     hipLaunchKernelGGL((k_free_energy<CM>), dim3(B), dim3(64 * P->C), 0, st, ws->pre, P->U, P->c, neg_free_energy, p_y, \
                        B, P->H, P->C, labels, ws->pos, ws->neg, ws->onehot)
@@ -1622,7 +1631,7 @@ int qbm_rbm_disc_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const flo
     g.gc = nullptr;  // written by k_disc_class_grad above
     if (fuse) g.gW = nullptr;
     qbm_rbm_params aux{nullptr, nullptr, P->d, P->U, nullptr, P->V, P->H, P->C};
-    if (int rc = launch_grad(P->V, P->H, P->C, B, x, QBM_F32, ws->onehot, ws->pos, x, QBM_F32, nullptr, ws->neg, &g,
+    if (int rc = launch_grad(P->V, P->H, P->C, B, x, x_dtype, ws->onehot, ws->pos, x, x_dtype, nullptr, ws->neg, &g,
                              fuse ? P->W : nullptr, fuse ? &aux : nullptr, lr, factor, batch_size, sparse_constant, st,
                              ws->cls_neg))
         return rc;

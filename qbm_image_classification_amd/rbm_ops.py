@@ -172,8 +172,9 @@ class HipRbmOps:
 
     # ---- training steps -----------------------------------------------------------------------
     def disc_step(self, P: ParamSet, G: GradSet, x, labels, apply_update, fuse, lr, factor, batch_size, sparse):
-        """One discriminative_training pass (src/ClassificationRBM.py:101-140). -> p(y|x) [B,C]"""
-        x = _f32(x, self.device)
+        """One discriminative_training pass (src/ClassificationRBM.py:101-140). -> p(y|x) [B,C]
+        x: fp32, or uint8 {0,1} (binary inputs stay bytes: the uint8 kernels, same values)."""
+        x, xd = _state(x, self.device)
         if not (torch.is_tensor(labels) and labels.dtype == torch.int32 and labels.device == self.device
                 and labels.is_contiguous()):
             labels = torch.as_tensor(labels).to(device=self.device, dtype=torch.int32).contiguous()
@@ -186,9 +187,9 @@ class HipRbmOps:
         ws = self._disc_ws[2]
         p = torch.empty(B, P.C, dtype=torch.float32, device=self.device)
         ps, gs = P.struct(), G.struct(with_gb=False)
-        check(self.lib.qbm_rbm_disc_step(C.byref(ps), C.byref(gs), ptr(x), ptr(labels), B, ptr(p), None, C.byref(ws),
-                                         int(apply_update), int(fuse), lr, factor, batch_size, sparse,
-                                         current_stream()), "qbm_rbm_disc_step")
+        check(self.lib.qbm_rbm_disc_step_ex(C.byref(ps), C.byref(gs), ptr(x), xd, ptr(labels), B, ptr(p), None, C.byref(ws),
+                                            int(apply_update), int(fuse), lr, factor, batch_size, sparse,
+                                            current_stream()), "qbm_rbm_disc_step_ex")
         return p
 
     def cd_step(self, P: ParamSet, G: GradSet, v0, y0, k, seed, offset, row0, chain_v, chain_y, fuse, lr, factor,

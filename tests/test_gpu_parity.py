@@ -172,12 +172,15 @@ def test_discriminative_step_bitwise(ops, oracle, V, H, C, B):
     from qbm_image_classification_amd.rbm_ops import GradSet
 
     W, b, d, U, c = synth_params(V, H, C, 300 + V + H)
-    _, x_grey, _, labels, _ = synth_inputs(B, V, H, C, 9)
-    for fuse in (False, True):
+    v_bin, x_grey, _, labels, _ = synth_inputs(B, V, H, C, 9)
+    # greyscale fp32 inputs (what the reference trains on), and binary inputs handed over as uint8 {0,1} (qbm_rbm_disc_step_ex:
+    # the uint8 kernels) -- the oracle sees the same values as fp32
+    for fuse, x_in, x_ref in ((False, dev(ops, x_grey), x_grey), (True, dev(ops, x_grey), x_grey),
+                              (False, dev(ops, v_bin.astype(np.uint8)), v_bin), (True, dev(ops, v_bin.astype(np.uint8)), v_bin)):
         P = P_of(ops, W, b, d, U, c)
         G = GradSet(V, H, C, ops.device)
-        p = ops.disc_step(P, G, dev(ops, x_grey), torch.from_numpy(labels), True, fuse, 0.05, 1.0, float(B), 0.001)
-        gW, gd, gU, gc, po, _ = oracle.rbm_disc_grad(x_grey, labels, W, d, U, c)
+        p = ops.disc_step(P, G, x_in, torch.from_numpy(labels), True, fuse, 0.05, 1.0, float(B), 0.001)
+        gW, gd, gU, gc, po, _ = oracle.rbm_disc_grad(x_ref, labels, W, d, U, c)
         assert_bitwise(p, po, "p(y|x)")
         if not fuse:
             assert_bitwise(G.gW, gW, "gW")

@@ -66,6 +66,11 @@ def main():
         us = timeit(lambda: ops.disc_step(P, G, x, lab, True, True, 0.05, 1.0, float(B), 0.0))
         out.append({"what": f"discriminative_training step 784x512 B=256 C={C} (reference CPU: 167/235 ms)", "us_per_step": round(us, 2)})
         print(json.dumps(out[-1]), flush=True)
+        if C == 10:
+            x8 = (ops.uniform(5, 0, 0, B, V) < 0.3).to(torch.uint8)
+            us8 = timeit(lambda: ops.disc_step(P, G, x8, lab, True, True, 0.05, 1.0, float(B), 0.0))
+            out.append({"what": f"discriminative_training step 784x512 B=256 C={C}, binary inputs as uint8", "us_per_step": round(us8, 2)})
+            print(json.dumps(out[-1]), flush=True)
         us = timeit(lambda: ops.free_energy(P, x))
         out.append({"what": f"sample_class_given_x 784x512 B=256 C={C} (reference CPU: 29/108 ms)", "us_per_call": round(us, 2)})
         print(json.dumps(out[-1]), flush=True)
