@@ -12,8 +12,8 @@ stats() {  # $1 tag, rest: program
   f=$(ls -t $(find $ROOT/gpurun_out/prof_$tag -name "*kernel_stats.csv") 2>/dev/null | head -1)
   [ -n "$f" ] && cp $f $OUT/${R}_${tag}_kernel_stats.csv
 }
-stats bench_eager python3 $ROOT/bench.py --steps 500 --warmup 50 --graph 0 --no-cpu-baseline
-cp $ROOT/gpurun_out/prof_bench_eager.out $OUT/${R}_bench_eager_under_rocprof.json
+stats bench python3 $ROOT/bench.py --steps 800 --warmup 80 --no-cpu-baseline      # the bench as it is run: hipGraph replays
+cp $ROOT/gpurun_out/prof_bench.out $OUT/${R}_bench_under_rocprof.json
 stats other_configs python3 $ROOT/tools/bench_configs.py
 cp $ROOT/gpurun_out/prof_other_configs.out $OUT/${R}_other_configs_under_rocprof.jsonl
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU" "GRBM_GUI_ACTIVE"; do
