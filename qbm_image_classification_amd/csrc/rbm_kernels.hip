@@ -324,8 +324,9 @@ __device__ __forceinline__ void class_row_draw(float* __restrict__ p_out, float*
 // one of class_row_energies' wavefronts does for its classes; lane 0 normalises and draws like class_row_draw.
 template <class TH, int CM, bool SC1 = false>
 __device__ __forceinline__ void class_row_wave(const void* __restrict__ h, const float* __restrict__ U,
-                                               const float* __restrict__ cb, float* __restrict__ y_out, int i, int H, int C,
-                                               uint64_t seed, uint64_t offset, uint32_t row0, int lane)
+                                               const float* __restrict__ cb, float* __restrict__ p_out,
+                                               float* __restrict__ y_out, int i, int H, int C, uint64_t seed, uint64_t offset,
+                                               uint32_t row0, int lane)
 {
     float e[CM];
 #pragma unroll
@@ -363,13 +364,16 @@ __device__ __forceinline__ void class_row_wave(const void* __restrict__ h, const
     for (int c = 0; c < CM; ++c) {
         if (c < C) {
             const float p = ev[c] / denom;
+            if (p_out) p_out[(long)i * C + c] = p;
             cum = cum + p;
             if (!done && u < cum) { pick = c; done = true; }
         }
     }
+    if (y_out) {
 #pragma unroll
-    for (int c = 0; c < CM; ++c)
-        if (c < C) y_out[(long)i * C + c] = (c == pick) ? 1.f : 0.f;
+        for (int c = 0; c < CM; ++c)
+            if (c < C) y_out[(long)i * C + c] = (c == pick) ? 1.f : 0.f;
+    }
 }
 
 template <class TH, int CM>
@@ -488,10 +492,18 @@ template <class TA, bool FAST, int CM>
 __global__ __launch_bounds__(64 * V_NQ) void k_visible(VisibleArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    if ((int)blockIdx.x < a.n_aux) {  // aux workgroup (dealt first): class conditional of one row, by its first 4 wavefronts
-        if (threadIdx.x >= 256) return;   // (a wavefront that has ended does not take part in the workgroup's barriers)
-        class_row<TA, CM>(a.h, a.U, a.cb, a.py, a.ys, (int)blockIdx.x, a.H, a.C, a.seed, a.offset_y, a.row0,
-                          reinterpret_cast<float*>(lds));
+    if ((int)blockIdx.x < a.n_aux) {  // aux workgroup (dealt first): the class conditional
+        if (a.n_aux == a.B) {   // one row per workgroup, its classes dealt to the first 4 wavefronts: the shortest path to y
+            if (threadIdx.x >= 256) return;   // (a wavefront that has ended does not take part in the workgroup's barriers)
+            class_row<TA, CM>(a.h, a.U, a.cb, a.py, a.ys, (int)blockIdx.x, a.H, a.C, a.seed, a.offset_y, a.row0,
+                              reinterpret_cast<float*>(lds));
+            return;
+        }
+        // large minibatches: 8 rows per workgroup, one per wavefront (an eighth of the workgroups to dispatch; at B = 2048
+        // the step takes 128 us instead of 136; at B = 256 the longer per-row latency costs 0.6 us)
+        const int i = (int)blockIdx.x * V_NQ + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+        if (i < a.B)
+            class_row_wave<TA, CM>(a.h, a.U, a.cb, a.py, a.ys, i, a.H, a.C, a.seed, a.offset_y, a.row0, (int)threadIdx.x & 63);
         return;
     }
     QBM_STAMP(10);
@@ -667,7 +679,7 @@ __global__ __launch_bounds__(512) void k_chain(ChainArgs a)
             const int r = n_free > 0 ? (j - nNv) * 8 + wv : (wv == 0 ? j : 32);
             if (j >= nNv || n_free == 0)
                 for (int rr = r; rr >= 0 && rr < 32; rr += 8 * (n_free > 0 ? n_free : 32))
-                    class_row_wave<uint8_t, CM, true>(a.h, a.U, a.c, yout, g * 32 + rr, a.H, a.C, a.seed, off - 1, a.row0,
+                    class_row_wave<uint8_t, CM, true>(a.h, a.U, a.c, nullptr, yout, g * 32 + rr, a.H, a.C, a.seed, off - 1, a.row0,
                                                       (int)threadIdx.x & 63);
         }
     }
@@ -1241,7 +1253,7 @@ int launch_visible_t(const qbm_rbm_params* P, const void* h, int B, float* p_v, 
                   // pairs of visible units: 8-byte accesses to p / v_f32 / b, 2-byte accesses to v_u8
                   (P->V % 2 == 0) && (!p_v || aligned8(p_v)) && (!v_s || aligned8(v_s)) && (!v_s8 || aligned2(v_s8)) &&
                       aligned8(P->b),
-                  P->U, P->c, p_y, y1hot, P->C, offset_y, with_class ? B : 0};
+                  P->U, P->c, p_y, y1hot, P->C, offset_y, with_class ? (B <= 512 ? B : (B + NQ - 1) / NQ) : 0};
     const bool fast = (P->H % 16 == 0) && aligned16(h) && aligned16(P->W) && small2g((long)B * P->H, ASZ) &&
                       small2g((long)P->V * P->H, 4);
     const int grid = nM * nN + a.n_aux;
