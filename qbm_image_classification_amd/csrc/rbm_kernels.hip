@@ -492,16 +492,20 @@ template <class TA, bool FAST, int CM>
 __global__ __launch_bounds__(64 * V_NQ) void k_visible(VisibleArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    if ((int)blockIdx.x < a.n_aux) {  // aux workgroup (dealt first): the class conditional
-        if (a.n_aux == a.B) {   // one row per workgroup, its classes dealt to the first 4 wavefronts: the shortest path to y
-            if (threadIdx.x >= 256) return;   // (a wavefront that has ended does not take part in the workgroup's barriers)
+    const int nMs = (a.B + 16 * V_MT - 1) / (16 * V_MT), nNs = (a.V + 16 * V_NT - 1) / (16 * V_NT);
+    if (a.n_aux == a.B) {
+        // aux workgroups dealt first: the class conditional of one row each, its classes dealt to the first 4 wavefronts --
+        // the shortest path to y (a wavefront that has ended takes no part in the workgroup's barriers)
+        if ((int)blockIdx.x < a.n_aux) {
+            if (threadIdx.x >= 256) return;
             class_row<TA, CM>(a.h, a.U, a.cb, a.py, a.ys, (int)blockIdx.x, a.H, a.C, a.seed, a.offset_y, a.row0,
                               reinterpret_cast<float*>(lds));
             return;
         }
-        // large minibatches: 8 rows per workgroup, one per wavefront (an eighth of the workgroups to dispatch; at B = 2048
-        // the step takes 128 us instead of 136; at B = 256 the longer per-row latency costs 0.6 us)
-        const int i = (int)blockIdx.x * V_NQ + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    } else if ((int)blockIdx.x >= nMs * nNs) {
+        // large minibatches: 8 rows per aux workgroup, one per wavefront, dealt BEHIND the strips (they fill the ragged end of
+        // the launch instead of standing in front of it)
+        const int i = ((int)blockIdx.x - nMs * nNs) * V_NQ + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
         if (i < a.B)
             class_row_wave<TA, CM>(a.h, a.U, a.cb, a.py, a.ys, i, a.H, a.C, a.seed, a.offset_y, a.row0, (int)threadIdx.x & 63);
         return;
@@ -509,9 +513,8 @@ __global__ __launch_bounds__(64 * V_NQ) void k_visible(VisibleArgs a)
     QBM_STAMP(10);
     asm volatile("" ::"s"(a.h), "s"(a.W), "s"(a.b), "s"(a.p), "s"(a.s), "s"(a.s8), "s"(a.B), "s"(a.V), "s"(a.H), "s"(a.KP),
                  "s"(a.seed), "s"(a.offset), "s"(a.row0));   // all arguments in one scalar-cache round trip (see k_hidden)
-    const int nM = (a.B + 16 * V_MT - 1) / (16 * V_MT), nN = (a.V + 16 * V_NT - 1) / (16 * V_NT);
     int ms, ns;
-    strip_coords(nM, nN, ms, ns, a.n_aux);
+    strip_coords(nMs, nNs, ms, ns, a.n_aux == a.B ? a.n_aux : 0);
     visible_body<TA, FAST, V_MT, V_NT>(a, ms, ns, lds);
 }
 
