@@ -1214,6 +1214,9 @@ int launch_hidden_t(const qbm_rbm_params* P, const void* v, const float* y, int 
     const bool cls = mode == 0 && y;
     a.epiDma = fast && NT == 1 && MT == 2 && aligned16(P->d) &&
                (!cls || (5 * P->C + 4 <= 64 && ((long)B * P->C) % 4 == 0 && aligned16(y) && aligned16(P->U)));
+    // ... and without the 8 KB of epilogue scratch three of them fit (B = 2048: 124 us per CD-1 step instead of 128): the
+    // epilogue operands of those workgroups come by ordinary loads
+    if (ASZ == 1 && fast && nM * nN > 256) a.epiDma = false;
     if (a.epiDma) {
         a.ldsCls = (int)lds;
         lds += kScratch;
