@@ -9,7 +9,9 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer into caller-owned memory (e.g. torch tensor .data_ptr());
- *     nothing is allocated, freed or cached inside the library, there is no global state;
+ *     nothing is allocated or freed inside the library.  Process-wide state: ONE switch, qbm_rbm_fused_chain_mode (which
+ *     launch sequence a CD-k chain takes; both give the same bits), and a per-device cache of one device attribute
+ *     (the CU count that switch consults).  Everything else lives in the caller's buffers;
  *   - all matrices are dense row-major float32 unless stated otherwise;
  *   - `stream` is a hipStream_t (NULL = the default stream); every call only enqueues work on it,
  *     never synchronises, and is legal inside hipStreamBeginCapture/EndCapture;
@@ -29,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QBM_ABI_VERSION 10
+#define QBM_ABI_VERSION 11
 #define QBM_MAX_CLASSES 15 /* class rows + the bias row share one 16-row gradient tile */
 #define QBM_MAX_QUBO_VARS 1024
 
@@ -68,6 +70,11 @@ typedef struct {
     float* gd;
     float* gU;
     float* gc;
+    float* n_rows; /* optional, 1 float: the gradient launch of qbm_rbm_cd_step / qbm_rbm_disc_step / qbm_rbm_two_phase_grad
+                    * stores the number of rows it summed over (0 for an empty shard; -inf when the one-launch chain in
+                    * front of it gave up, see qbm_rbm_cd_workspace.sync).  The data-parallel path keeps it right behind the
+                    * gradient blocks, so ONE all-reduce yields the global batch size on the device
+                    * (qbm_rbm_update_dev) -- no host round trip per step. */
 } qbm_rbm_grads;
 
 QBM_API int qbm_abi_version(void);
@@ -134,6 +141,15 @@ QBM_API int qbm_rbm_two_phase_grad(int V, int H, int C, int B, const void* A0, i
 QBM_API int qbm_rbm_update(const qbm_rbm_params* P, const qbm_rbm_grads* G, float lr, float factor,
                            float batch_size, float sparse_constant, void* stream);
 
+/* The same with the batch size read from DEVICE memory when batch_size_dev is non-NULL (1 float: the all-reduced
+ * qbm_rbm_grads.n_rows of the data-parallel step; `batch_size` is then ignored).  A value that is not a
+ * positive finite number makes the launch a no-op: some rank's one-launch chain gave up (its n_rows is -inf), so every
+ * rank skips this update alike.  chain_status non-NULL: the status word of a fused chain launch
+ * (qbm_rbm_cd_workspace.sync + 512); non-zero = no-op. */
+QBM_API int qbm_rbm_update_dev(const qbm_rbm_params* P, const qbm_rbm_grads* G, float lr, float factor, float batch_size,
+                               const float* batch_size_dev, float sparse_constant, const uint32_t* chain_status,
+                               void* stream);
+
 /* ---- composites: launch sequences on `stream` (graph-capturable) ---------------------------- */
 
 /* fp32 -> uint8 conversion of a {0,1} tensor (n elements), for callers that hold binary data as floats */
@@ -148,9 +164,15 @@ typedef struct {
     float* phk;   /* [B,H] */
     uint32_t* sync; /* [QBM_CD_SYNC_WORDS] uint32, zeroed once by the caller and then left alone, or NULL: state of the
                      * fused chain kernel (round flags of its XCD-local barriers, the XCC ids, status word at index 512:
-                     * 0 = fine, 1 = a barrier timed out, 2 = workgroups of a row block on different XCDs -> results of
-                     * that launch are invalid, run with QBM_FUSED_CHAIN=0).  NULL = always the launch-per-phase path.
-                     * One buffer per stream of concurrent work. */
+                     * 0 = fine, 1 = a barrier timed out, 2 = workgroups of a row block on different XCDs; words 513 / 514:
+                     * `offset` (low / high half) of the launch that gave up).  FAIL-SAFE: the gradient launch of
+                     * qbm_rbm_cd_step behind a chain that gave up writes nothing (parameters and gradient blocks keep their
+                     * values, n_rows becomes -inf), and every later one-launch chain and gradient on this buffer does
+                     * nothing either, until the caller has re-zeroed the buffer -- a failed chain never reaches the
+                     * parameters.  The caller then repeats the skipped steps with qbm_rbm_fused_chain_mode(0): same draws,
+                     * same bits (rbm_ops.HipRbmOps.check_chain_status does exactly that).  NULL = always the
+                     * launch-per-phase path.  One buffer per stream of concurrent work; workspaces of different
+                     * shapes on one stream may share it. */
 } qbm_rbm_cd_workspace;
 #define QBM_CD_SYNC_WORDS 576
 

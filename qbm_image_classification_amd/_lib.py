@@ -8,7 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libqbm_hip.so")
 
-QBM_ABI_VERSION = 10
+QBM_ABI_VERSION = 11
 QBM_MAX_CLASSES = 15
 QBM_F32, QBM_U8 = 0, 1
 
@@ -23,7 +23,8 @@ class RbmParams(C.Structure):
 
 
 class RbmGrads(C.Structure):
-    _fields_ = [("gW", C.c_void_p), ("gb", C.c_void_p), ("gd", C.c_void_p), ("gU", C.c_void_p), ("gc", C.c_void_p)]
+    _fields_ = [("gW", C.c_void_p), ("gb", C.c_void_p), ("gd", C.c_void_p), ("gU", C.c_void_p), ("gc", C.c_void_p),
+                ("n_rows", C.c_void_p)]   # optional: receives the row count of the gradient launch (data-parallel path)
 
 
 class CdWorkspace(C.Structure):
@@ -61,6 +62,7 @@ SIGNATURES = {
     "qbm_rbm_sample_visible_class_ex": [_PP, _p, _i, _i, _p, _p, _p, _p, _p, _u64, _u64, _u64, _u32, _p],
     "qbm_f32_to_u8": [_p, _p, C.c_long, _p],
     "qbm_rbm_update": [_PP, _GP, _f, _f, _f, _f, _p],
+    "qbm_rbm_update_dev": [_PP, _GP, _f, _f, _f, _p, _f, _p, _p],
     "qbm_rbm_fused_chain_mode": [_i],
     "qbm_rbm_cd_chain": [_PP, _p, _i, _p, _i, _i, _u64, _u64, _u32, _p, _p, C.POINTER(CdWorkspace), _p],
     "qbm_rbm_cd_step": [_PP, _GP, _p, _i, _p, _i, _i, _u64, _u64, _u32, _p, _p, C.POINTER(CdWorkspace), _i, _f, _f,

@@ -77,11 +77,18 @@ class ClassificationRBM:
         self._chain_v = None      # persistent chains (PCD)
         self._chain_y = None
         self._rank_rows = None    # nominal minibatch rows per rank (set by train_rbm from the loader's batch_size)
+        self._pset = None
+        if self.data_parallel and hasattr(self.ops, "status_agree"):
+            self.ops.status_agree = self._agree_chain_status
 
     # ------------------------------------------------------------------------------------------
     def _params(self) -> ParamSet:
-        # rebuilt per call so that user code may rebind the public attributes, as with the reference
-        return ParamSet(self.weights, self.visible_bias, self.hidden_bias, self.class_weights, self.class_bias)
+        # user code may rebind the public attributes, as with the reference: the ParamSet (and its ctypes struct) is kept as
+        # long as the five attributes are the same tensor objects
+        tensors = (self.weights, self.visible_bias, self.hidden_bias, self.class_weights, self.class_bias)
+        if self._pset is None or not self._pset.same_tensors(*tensors):
+            self._pset = ParamSet(*tensors)
+        return self._pset
 
     def _next_offset(self, n=1):
         o = self._draw_offset
@@ -131,14 +138,33 @@ class ClassificationRBM:
         self.ops.update(self._params(), self._grads, float(self.learning_rate), float(factor), float(batch_size),
                         float(self.sparse_constant), with_gb=with_gb)
 
-    def _allreduce_grads(self, local_rows):
-        """ONE collective per step: the flat gradient buffer, whose last element carries the local row count
-        (a rank with an empty shard contributes zeros: the C entry points zero the blocks at B == 0)."""
+    def _allreduce_grads(self):
+        """ONE collective per step: the flat gradient buffer, whose last element carries the local row count -- written by
+        the gradient launch itself (qbm_rbm_grads.n_rows; a rank with an empty shard contributes zeros: the C entry points
+        zero the blocks at B == 0).  The sum stays ON THE DEVICE: qbm_rbm_update_dev reads the global batch size from
+        there, so a data-parallel step has no host round trip."""
         import torch.distributed as dist
 
-        self._grads.count.fill_(float(local_rows))
         dist.all_reduce(self._grads.flat, op=dist.ReduceOp.SUM)  # RCCL over xGMI
-        return float(self._grads.count.item())
+
+    def _agree_chain_status(self, st, off_lo):
+        """Collective behind HipRbmOps.check_chain_status: the group's status (max over ranks) and the draw offset of the
+        FIRST step any rank's one-launch chain lost (that rank's update was a no-op, and through the -inf row count so was
+        every other rank's): all ranks repeat from there."""
+        import torch.distributed as dist
+
+        dev = self.device if dist.get_backend() != "gloo" else torch.device("cpu")
+        t = torch.tensor([st, (1 << 32) - off_lo if st else 0], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        st, inv = (int(x) for x in t.tolist())
+        return st, ((1 << 32) - inv) & 0xFFFFFFFF if st else 0
+
+    def _world(self):
+        if not self.data_parallel:
+            return 1
+        import torch.distributed as dist
+
+        return dist.get_world_size()
 
     def _rank_row_offset(self, local_rows):
         """Global index, inside the current global minibatch, of this rank's first row: rank * NOMINAL rows per rank
@@ -157,9 +183,9 @@ class ClassificationRBM:
         lr, sp = float(self.learning_rate), float(self.sparse_constant)
         if self.data_parallel:
             p = self.ops.disc_step(P, self._grads, input_data, class_label, False, False, lr, float(factor),
-                                   float(batch_size), sp)
-            global_rows = self._allreduce_grads(batch_size)
-            self.ops.update(P, self._grads, lr, float(factor), global_rows, sp, with_gb=False)
+                                   float(batch_size), sp, with_count=True)
+            self._allreduce_grads()
+            self.ops.update(P, self._grads, lr, float(factor), 0.0, sp, with_gb=False, count_dev=self._grads.count)
         else:
             p = self.ops.disc_step(P, self._grads, input_data, class_label, True, not self.keep_grads, lr,
                                    float(factor), float(batch_size), sp)
@@ -194,21 +220,26 @@ class ClassificationRBM:
         cv = self._chain_v[:batch_size] if self.persistent else None
         cy = self._chain_y[:batch_size] if self.persistent else None
         self.visible_bias_grad = self._grads.gb
+        G, k, seed, f, bs = self._grads, self.k, self.seed, float(factor), float(batch_size)
+        # `step` is also what HipRbmOps.check_chain_status calls to repeat this minibatch on the launch-per-phase path should
+        # its one-launch chain have given up (its gradient and update launches were then no-ops)
         if self.data_parallel:
-            self.ops.cd_step(P, self._grads, v0, y0, self.k, self.seed, offset, row0, cv, cy, False, lr,
-                             float(factor), float(batch_size), sp)
-            global_rows = self._allreduce_grads(batch_size)
-            self.ops.update(P, self._grads, lr, float(factor), global_rows, sp)
-            self._rows_seen += int(global_rows)
-        else:
-            if self.keep_grads:
-                self.ops.cd_step(P, self._grads, v0, y0, self.k, self.seed, offset, row0, cv, cy, False, lr,
-                                 float(factor), float(batch_size), sp)
-                self.ops.update(P, self._grads, lr, float(factor), float(batch_size), sp)
-            else:  # W update fused into the gradient pass, remaining blocks by one update launch
-                self.ops.cd_step(P, self._grads, v0, y0, self.k, self.seed, offset, row0, cv, cy, True, lr,
-                                 float(factor), float(batch_size), sp)
-            self._rows_seen += batch_size
+            def step():
+                self.ops.cd_step(P, G, v0, y0, k, seed, offset, row0, cv, cy, False, lr, f, bs, sp, with_count=True, replay=step)
+                self._allreduce_grads()
+                self.ops.update(P, G, lr, f, 0.0, sp, count_dev=G.count)   # global batch size read on the device
+        elif self.keep_grads:
+            def step():
+                self.ops.cd_step(P, G, v0, y0, k, seed, offset, row0, cv, cy, False, lr, f, bs, sp, replay=step)
+                self.ops.update(P, G, lr, f, bs, sp, guard_chain=True)
+        else:  # every update fused into the gradient launch
+            def step():
+                self.ops.cd_step(P, G, v0, y0, k, seed, offset, row0, cv, cy, True, lr, f, bs, sp, replay=step)
+        step()
+        # Philox rows advance by the NOMINAL global minibatch (the loader's batch_size x ranks; a short last minibatch
+        # included): known on the host of every rank without asking the device for the all-reduced row count
+        nominal = int(self._rank_rows if self._rank_rows else batch_size)
+        self._rows_seen += nominal * self._world()
         return None
 
     def _sigmoid(self, x):

@@ -576,7 +576,16 @@ __device__ __forceinline__ uint32_t load_sc1(const uint32_t* p)
 }
 
 // Barrier among the 32 workgroups of a group (every thread of the workgroup calls it).  false: the spin ran out.
-__device__ __forceinline__ bool group_barrier(uint32_t* flags, int j, uint32_t target, uint32_t* status, uint32_t* s_ok)
+// Giving up: the status word (sync[512]) and, for the host's replay, the draw offset of the launch (sync[513], [514]).
+__device__ __forceinline__ void chain_give_up(uint32_t* status, uint32_t code, uint64_t offset)
+{
+    status[1] = (uint32_t)offset;
+    status[2] = (uint32_t)(offset >> 32);
+    __hip_atomic_store(status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ bool group_barrier(uint32_t* flags, int j, uint32_t target, uint32_t* status, uint32_t* s_ok,
+                                              uint64_t offset)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's stores have reached the L2
     __syncthreads();
@@ -590,7 +599,7 @@ __device__ __forceinline__ bool group_barrier(uint32_t* flags, int j, uint32_t t
             if (spins > kChainSpin) { ok = false; break; }
         }
         if (lane == 0) {
-            if (!ok) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!ok) chain_give_up(status, 1u, offset);
             *s_ok = ok ? 1u : 0u;
         }
     }
@@ -608,6 +617,11 @@ __global__ __launch_bounds__(512) void k_chain(ChainArgs a)
     uint32_t* flags = a.sync + g * 32;
     uint32_t* ids = a.sync + 256 + g * 32;
     uint32_t* status = a.sync + 512;
+    // A launch that gave up leaves the status word set and the round flags of its group ragged: until the host has looked
+    // (rbm_ops.check_chain_status re-zeroes the buffer and replays the steps on the launch-per-phase path) every later
+    // launch on this workspace does nothing -- and so do the k_grad / k_update launches behind it, which read the same word
+    // (GradArgs::status): a failed chain never reaches the parameters.
+    if (load_sc1(status) != 0u) return;
     uint32_t round = flags[j];   // my last round of the previous launch: the same in every word of the line
     QBM_STAMP(5);
     int n_bar = 0;   // (diagnostic builds stamp the first two barriers: slots 6/7 and 8/9)
@@ -646,7 +660,7 @@ __global__ __launch_bounds__(512) void k_chain(ChainArgs a)
         if (sync_first) {
             ++round;
             if (n_bar < 2) QBM_STAMP(6 + 2 * n_bar);
-            if (!group_barrier(flags, j, round, status, &s_ok)) return;
+            if (!group_barrier(flags, j, round, status, &s_ok, a.offset)) return;
             if (n_bar < 2) QBM_STAMP(7 + 2 * n_bar);
             ++n_bar;
             if (!checked) {   // all 32 workgroups of the group on one XCD?
@@ -655,7 +669,7 @@ __global__ __launch_bounds__(512) void k_chain(ChainArgs a)
                     const uint32_t id = threadIdx.x < 32 ? load_sc1(&ids[threadIdx.x]) : my_xcc;
                     const bool same = __all((int)(id == my_xcc));
                     if (threadIdx.x == 0) {
-                        if (!same) __hip_atomic_store(status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (!same) chain_give_up(status, 2u, a.offset);
                         s_ok = same ? 1u : 0u;
                     }
                 }
@@ -875,6 +889,10 @@ struct GradArgs {
     bool vecO;
     const float* gUsub;                          // non-null: class-weight gradient = (phase0 - phase1) - gUsub
     int lds_group;                               // bytes of one group's LDS staging region
+    const uint32_t* status;                      // non-null: status word of the fused chain launch in front (sync[512]);
+                                                 // non-zero = that launch gave up: this launch writes nothing (but n_rows)
+    float* n_rows;                               // non-null: receives (float)B -- the data-parallel path all-reduces it with the
+                                                 // gradients -- or -inf when `status` is set (every rank then skips the update)
 };
 
 __device__ __forceinline__ float upd(float th, float g, const GradArgs& a, bool sparse)
@@ -924,6 +942,11 @@ __global__ __launch_bounds__(PAR ? 512 : 256) void k_grad(GradArgs a)
     const int grp = PAR ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;   // 0: phase-0 operands, 1: phase-1 operands
     char* lds = lds_all + (size_t)grp * a.lds_group;
     int blk = blockIdx.x;
+    if (a.status || a.n_rows) {   // (neither on the launch-per-phase single-GPU path: no load, no branch taken)
+        const uint32_t st = a.status ? *a.status : 0u;   // written by an earlier launch: a plain (scalar) load
+        if (blk == 0 && threadIdx.x == 0 && a.n_rows) *a.n_rows = st ? -__builtin_inff() : (float)a.B;
+        if (st) return;
+    }
     const ViewCContig P0{a.P0, a.H, a.H, a.B}, P1{a.P1, a.H, a.H, a.B};
     const typename CView<T0>::type D0{reinterpret_cast<const T0*>(a.A0), a.V, a.V, a.B};
     const typename CView<T1>::type D1{reinterpret_cast<const T1*>(a.A1), a.V, a.V, a.B};
@@ -1082,12 +1105,20 @@ struct UpdateArgs {
     int V, H, C;
     float lr, factor, bs, sparse;
     long first;  // first element of the concatenated range to touch (V*H when W is already updated)
+    const float* bs_dev;      // non-null: the batch size is read from device memory (the all-reduced row count of the
+                              // data-parallel step); not a positive finite number (a rank's fused chain gave up: -inf) = no-op
+    const uint32_t* status;   // non-null: status word of a fused chain launch; non-zero = no-op
 };
 
 __global__ __launch_bounds__(256) void k_update(UpdateArgs a)
 {
     const long nW = (long)a.V * a.H, nU = (long)a.C * a.H;
     const long total = nW + a.V + a.H + nU + a.C;
+    if (a.status && *a.status != 0u) return;
+    if (a.bs_dev) {
+        a.bs = *a.bs_dev;
+        if (!(a.bs > 0.f) || a.bs > 3.0e38f) return;
+    }
     for (long i = a.first + (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         float* th; const float* g; long k = i; bool sp = false;
         if (k < nW) { th = a.W; g = a.gW; }
@@ -1175,6 +1206,10 @@ int zero_grads(const qbm_rbm_params* P, const qbm_rbm_grads* G, hipStream_t st)
             hipError_t e = hipMemsetAsync(b.p, 0, b.n * sizeof(float), st);
             if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(gradient block)");
         }
+    if (G->n_rows) {   // no rows from this rank
+        hipError_t e = hipMemsetAsync(G->n_rows, 0, sizeof(float), st);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(row count)");
+    }
     return QBM_OK;
 }
 
@@ -1290,7 +1325,7 @@ int launch_visible(const qbm_rbm_params* P, const void* h, int h_dtype, int B, f
 template <class T0, class T1>
 int launch_grad_t(int V, int H, int C, int B, const void* A0, const float* Y0, const float* P0, const void* A1,
                   const float* Y1, const float* P1, const qbm_rbm_grads* G, float* W_fused, const qbm_rbm_params* aux_fused,
-                  float lr, float factor, float bs, float sparse, hipStream_t st, const float* gU_sub)
+                  float lr, float factor, float bs, float sparse, hipStream_t st, const float* gU_sub, const uint32_t* status)
 {
     constexpr int MT = G_MT, NT = G_NT;
     const int nM = (V + 16 * MT - 1) / (16 * MT), nN = (H + 16 * NT - 1) / (16 * NT);
@@ -1301,7 +1336,7 @@ int launch_grad_t(int V, int H, int C, int B, const void* A0, const float* Y0, c
                aux_fused ? aux_fused->U : nullptr, aux_fused ? aux_fused->c : nullptr,
                lr, factor, bs, sparse, B, V, H, C, panel_for<MT, NT, 4>(B),
                nN, want_b ? nM : 0, want_c ? (C + 16 * NT - 1) / (16 * NT) : 0,
-               (H % 4 == 0) && (!G->gW || aligned16(G->gW)) && (!W_fused || aligned16(W_fused)), gU_sub, 0};
+               (H % 4 == 0) && (!G->gW || aligned16(G->gW)) && (!W_fused || aligned16(W_fused)), gU_sub, 0, status, G->n_rows};
     const bool fast = (B % 16 == 0) && (V % 16 == 0) && (H % 4 == 0) && aligned16(A0) && aligned16(A1) && aligned16(P0) &&
                       aligned16(P1) && small2g((long)B * V, 4) && small2g((long)B * H, 4);
     const int grid = a.nU + a.nB + a.nC + nM * nN;
@@ -1335,10 +1370,11 @@ int launch_grad_t(int V, int H, int C, int B, const void* A0, const float* Y0, c
 
 int launch_grad(int V, int H, int C, int B, const void* A0, int d0, const float* Y0, const float* P0, const void* A1, int d1,
                 const float* Y1, const float* P1, const qbm_rbm_grads* G, float* W_fused, const qbm_rbm_params* aux_fused,
-                float lr, float factor, float bs, float sparse, hipStream_t st, const float* gU_sub = nullptr)
+                float lr, float factor, float bs, float sparse, hipStream_t st, const float* gU_sub = nullptr,
+                const uint32_t* status = nullptr)
 {
     if (C + 1 > 16) return fail(QBM_ERR_ARG, "two_phase_grad: at most 15 classes (class rows + the bias row share one 16-row tile)");
-#define QBM_G(T0, T1) launch_grad_t<T0, T1>(V, H, C, B, A0, Y0, P0, A1, Y1, P1, G, W_fused, aux_fused, lr, factor, bs, sparse, st, gU_sub)
+#define QBM_G(T0, T1) launch_grad_t<T0, T1>(V, H, C, B, A0, Y0, P0, A1, Y1, P1, G, W_fused, aux_fused, lr, factor, bs, sparse, st, gU_sub, status)
     if (d0 == QBM_U8) return d1 == QBM_U8 ? QBM_G(uint8_t, uint8_t) : QBM_G(uint8_t, float);
     return d1 == QBM_U8 ? QBM_G(float, uint8_t) : QBM_G(float, float);
 #undef QBM_G
@@ -1362,12 +1398,18 @@ int launch_chain_fused(const qbm_rbm_params* P, const void* v0, int v0_dtype, co
                        hipStream_t st, bool* done)
 {
     *done = false;
-    static const bool device_fits = [] {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return false;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-        return cus == 256;   // 8 XCDs x 32 CUs: one workgroup per CU, 32 per XCD
-    }();
+    // 8 XCDs x 32 CUs: one workgroup per CU, 32 per XCD -- asked of the device the call runs on, cached per device
+    // (0 = not asked yet, 1 = fits, 2 = does not)
+    static std::atomic<signed char> fits_cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return QBM_OK;
+    signed char fc = (dev >= 0 && dev < 64) ? fits_cache[dev].load(std::memory_order_relaxed) : (signed char)0;
+    if (fc == 0) {
+        int cus = 0;
+        fc = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus == 256) ? 1 : 2;
+        if (dev >= 0 && dev < 64) fits_cache[dev].store(fc, std::memory_order_relaxed);
+    }
+    const bool device_fits = fc == 1;
     const int mode = fused_chain_mode();
     // mode 1: where it is faster -- from two Gibbs iterations on (CD-1: the first hidden phase of the fused kernel streams all
     // of W into every XCD, 12.8 MB instead of 1.6, which costs what the two saved launch boundaries gain; measured
@@ -1525,13 +1567,19 @@ int qbm_rbm_two_phase_grad(int V, int H, int C, int B, const void* A0, int a0_dt
 int qbm_rbm_update(const qbm_rbm_params* P, const qbm_rbm_grads* G, float lr, float factor, float batch_size,
                    float sparse_constant, void* stream)
 {
+    return qbm_rbm_update_dev(P, G, lr, factor, batch_size, nullptr, sparse_constant, nullptr, stream);
+}
+
+int qbm_rbm_update_dev(const qbm_rbm_params* P, const qbm_rbm_grads* G, float lr, float factor, float batch_size,
+                       const float* batch_size_dev, float sparse_constant, const uint32_t* chain_status, void* stream)
+{
     if (int rc = check_params(P)) return rc;
     if (!G) return fail(QBM_ERR_ARG, "update: grads is null");
-    if (!(batch_size > 0.f)) return fail(QBM_ERR_ARG, "update: batch_size must be positive");
+    if (!batch_size_dev && !(batch_size > 0.f)) return fail(QBM_ERR_ARG, "update: batch_size must be positive");
     const long nW = (long)P->V * P->H;
     const long total = nW + P->V + P->H + (long)P->C * P->H + P->C;
     UpdateArgs a{P->W, P->b, P->d, P->U, P->c, G->gW, G->gb, G->gd, G->gU, G->gc, P->V, P->H, P->C,
-                 lr, factor, batch_size, sparse_constant, G->gW ? 0 : nW};
+                 lr, factor, batch_size, sparse_constant, G->gW ? 0 : nW, batch_size_dev, chain_status};
     const long n = total - a.first;
     const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(k_update, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
@@ -1549,10 +1597,11 @@ int qbm_f32_to_u8(const float* x, uint8_t* y, long n, void* stream)
     return QBM_OK;
 }
 
-int qbm_rbm_cd_chain(const qbm_rbm_params* P, const void* v0, int v0_dtype, const float* y0, int B, int k, uint64_t seed,
-                     uint64_t offset, uint32_t row0, uint8_t* chain_v, float* chain_y, const qbm_rbm_cd_workspace* ws,
-                     void* stream)
+static int cd_chain_impl(const qbm_rbm_params* P, const void* v0, int v0_dtype, const float* y0, int B, int k, uint64_t seed,
+                         uint64_t offset, uint32_t row0, uint8_t* chain_v, float* chain_y, const qbm_rbm_cd_workspace* ws,
+                         void* stream, bool* fused)
 {
+    *fused = false;
     if (int rc = check_params(P)) return rc;
     if (int rc = check_dtype(v0_dtype)) return rc;
     if (B <= 0) return B == 0 ? QBM_OK : fail(QBM_ERR_ARG, "B < 0");
@@ -1564,6 +1613,7 @@ int qbm_rbm_cd_chain(const qbm_rbm_params* P, const void* v0, int v0_dtype, cons
     {   // one launch for the whole chain where the shape allows it (B <= 256 in blocks of 32 rows, uint8 data)
         bool done = false;
         if (int rc = launch_chain_fused(P, v0, v0_dtype, y0, B, k, seed, offset, row0, chain_v, chain_y, ws, st, &done)) return rc;
+        *fused = done;
         if (done) return QBM_OK;
     }
     if (chain_v) {
@@ -1588,6 +1638,14 @@ int qbm_rbm_cd_chain(const qbm_rbm_params* P, const void* v0, int v0_dtype, cons
     return QBM_OK;
 }
 
+int qbm_rbm_cd_chain(const qbm_rbm_params* P, const void* v0, int v0_dtype, const float* y0, int B, int k, uint64_t seed,
+                     uint64_t offset, uint32_t row0, uint8_t* chain_v, float* chain_y, const qbm_rbm_cd_workspace* ws,
+                     void* stream)
+{
+    bool fused;
+    return cd_chain_impl(P, v0, v0_dtype, y0, B, k, seed, offset, row0, chain_v, chain_y, ws, stream, &fused);
+}
+
 int qbm_rbm_cd_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void* v0, int v0_dtype, const float* y0, int B,
                     int k, uint64_t seed, uint64_t offset, uint32_t row0, uint8_t* chain_v, float* chain_y,
                     const qbm_rbm_cd_workspace* ws, int fuse_update, float lr, float factor, float batch_size,
@@ -1596,15 +1654,17 @@ int qbm_rbm_cd_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void*
     if (!G) return fail(QBM_ERR_ARG, "cd_step: grads is null");
     if (!fuse_update && (!G->gW || !G->gb || !G->gd || !G->gU || !G->gc))
         return fail(QBM_ERR_ARG, "cd_step: all gradient blocks are required without fuse_update");
-    if (int rc = qbm_rbm_cd_chain(P, v0, v0_dtype, y0, B, k, seed, offset, row0, chain_v, chain_y, ws, stream)) return rc;
+    bool fused = false;
+    if (int rc = cd_chain_impl(P, v0, v0_dtype, y0, B, k, seed, offset, row0, chain_v, chain_y, ws, stream, &fused)) return rc;
     if (B == 0) return zero_grads(P, G, (hipStream_t)stream);
     if (!(batch_size > 0.f)) return fail(QBM_ERR_ARG, "cd_step: batch_size must be positive");
     qbm_rbm_grads g = *G;
     if (fuse_update) g.gW = nullptr;  // the whole update happens inside the gradient launch
-    // PCD: (v_k, y_k) live in the persistent chains
+    // PCD: (v_k, y_k) live in the persistent chains.  Behind the one-launch chain the gradient launch reads the chain's status
+    // word: a chain that gave up (or an earlier one on this workspace that did) never reaches gradients or parameters.
     return launch_grad(P->V, P->H, P->C, B, v0, v0_dtype, y0, ws->ph0, chain_v ? chain_v : ws->vk, QBM_U8,
                        chain_v ? chain_y : ws->yk, ws->phk, &g, fuse_update ? P->W : nullptr, fuse_update ? P : nullptr, lr,
-                       factor, batch_size, sparse_constant, (hipStream_t)stream);
+                       factor, batch_size, sparse_constant, (hipStream_t)stream, nullptr, fused ? ws->sync + 512 : nullptr);
 }
 
 int qbm_rbm_disc_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const float* x, const int32_t* labels, int B,

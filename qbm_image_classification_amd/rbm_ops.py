@@ -23,9 +23,15 @@ class ParamSet:
         for t in (W, b, d, U, c):
             if t.dtype != torch.float32:
                 raise _lib.QbmHipError("parameters must be float32")
+        self._struct = None
 
     def struct(self) -> RbmParams:
-        return RbmParams(ptr(self.W), ptr(self.b), ptr(self.d), ptr(self.U), ptr(self.c), self.V, self.H, self.C)
+        if self._struct is None:   # built once per ParamSet (the tensors of a ParamSet never change identity)
+            self._struct = RbmParams(ptr(self.W), ptr(self.b), ptr(self.d), ptr(self.U), ptr(self.c), self.V, self.H, self.C)
+        return self._struct
+
+    def same_tensors(self, W, b, d, U, c) -> bool:
+        return self.W is W and self.b is b and self.d is d and self.U is U and self.c is c
 
 
 class GradSet:
@@ -45,10 +51,16 @@ class GradSet:
         self.gU = self.flat[o:o + C * H].view(C, H); o += C * H
         self.gc = self.flat[o:o + C]; o += C
         self.count = self.flat[o:o + 1]
+        self._structs = {}
 
-    def struct(self, with_gW=True, with_gb=True) -> RbmGrads:
-        return RbmGrads(ptr(self.gW) if with_gW else None, ptr(self.gb) if with_gb else None, ptr(self.gd),
-                        ptr(self.gU), ptr(self.gc))
+    def struct(self, with_gW=True, with_gb=True, with_count=False) -> RbmGrads:
+        """with_count: the gradient launch stores its row count in `count` (qbm_rbm_grads.n_rows): the data-parallel path."""
+        key = (with_gW, with_gb, with_count)
+        st = self._structs.get(key)
+        if st is None:
+            st = self._structs[key] = RbmGrads(ptr(self.gW) if with_gW else None, ptr(self.gb) if with_gb else None,
+                                               ptr(self.gd), ptr(self.gU), ptr(self.gc), ptr(self.count) if with_count else None)
+        return st
 
 
 def _f32(t, device):
@@ -80,6 +92,11 @@ class HipRbmOps:
             raise _lib.QbmHipError("no ROCm device visible: the HIP path cannot run (there is no CPU fallback)")
         self.device = torch.device(device)
         self._disc_ws = None
+        self._cd_ws = None       # (key, workspace) of the last cd_step that used a cached workspace
+        self._cd_wss = {}        # minibatch shape -> workspace (they share the one sync buffer)
+        self._sync = None        # state of the fused chain kernel (round flags, status word)
+        self._pending = []       # (draw offset, replay) of the steps since the last look at the status word
+        self.status_agree = None # data-parallel callers: (status, offset) -> the group's (collective; see ClassificationRBM)
 
     # ---- conditionals -------------------------------------------------------------------------
     def sample_hidden(self, P: ParamSet, v, y=None, seed=0, offset=0, row0=0, want_p=True, want_s=False):
@@ -171,9 +188,11 @@ class HipRbmOps:
         return nf, p
 
     # ---- training steps -----------------------------------------------------------------------
-    def disc_step(self, P: ParamSet, G: GradSet, x, labels, apply_update, fuse, lr, factor, batch_size, sparse):
+    def disc_step(self, P: ParamSet, G: GradSet, x, labels, apply_update, fuse, lr, factor, batch_size, sparse,
+                  with_count=False):
         """One discriminative_training pass (src/ClassificationRBM.py:101-140). -> p(y|x) [B,C]
-        x: fp32, or uint8 {0,1} (binary inputs stay bytes: the uint8 kernels, same values)."""
+        x: fp32, or uint8 {0,1} (binary inputs stay bytes: the uint8 kernels, same values).
+        with_count: the gradient launch also stores its row count in G.count (the data-parallel path all-reduces it)."""
         x, xd = _state(x, self.device)
         if not (torch.is_tensor(labels) and labels.dtype == torch.int32 and labels.device == self.device
                 and labels.is_contiguous()):
@@ -186,34 +205,72 @@ class HipRbmOps:
             self._disc_ws = (key, bufs, DiscWorkspace(*(ptr(t) for t in bufs)))
         ws = self._disc_ws[2]
         p = torch.empty(B, P.C, dtype=torch.float32, device=self.device)
-        ps, gs = P.struct(), G.struct(with_gb=False)
+        ps, gs = P.struct(), G.struct(with_gb=False, with_count=with_count)
         check(self.lib.qbm_rbm_disc_step_ex(C.byref(ps), C.byref(gs), ptr(x), xd, ptr(labels), B, ptr(p), None, C.byref(ws),
                                             int(apply_update), int(fuse), lr, factor, batch_size, sparse,
                                             current_stream()), "qbm_rbm_disc_step_ex")
         return p
 
     def cd_step(self, P: ParamSet, G: GradSet, v0, y0, k, seed, offset, row0, chain_v, chain_y, fuse, lr, factor,
-                batch_size, sparse, ws=None):
+                batch_size, sparse, ws=None, with_count=False, replay=None):
         """CD-k / PCD step: chain + gradient (+ fused update when `fuse`).
         v0: fp32 or uint8 {0,1} [B,V]; chain_v: uint8 [B,V] persistent state (PCD) or None.
+        with_count: the gradient launch also stores its row count in G.count (the data-parallel path all-reduces it).
+        replay: what to call to repeat this step should its one-launch chain give up (default: this call again; the
+        data-parallel caller passes chain + all-reduce + update).
         -> (ph0 f32, h u8, vk u8, yk f32, phk f32); with persistent chains (v_k, y_k) ARE chain_v / chain_y."""
         v0, vd = _state(v0, self.device)
         y0 = _f32(y0, self.device)
         B = v0.shape[0]
         if chain_v is not None and chain_v.dtype != torch.uint8:
             raise _lib.QbmHipError("persistent chain state must be uint8")
-        if ws is None:   # scratch reused from step to step (stream-ordered), like the discriminative step's
-            key = (B, P.V, P.H, P.C)
-            if getattr(self, "_cd_ws", None) is None or self._cd_ws[0] != key:
-                self._cd_ws = (key, self.cd_workspace(P, B))
-            ws = self._cd_ws[1]
-        cws = CdWorkspace(*(ptr(t) for t in ws))
-        ps, gs = P.struct(), G.struct()
-        check(self.lib.qbm_rbm_cd_step(C.byref(ps), C.byref(gs), ptr(v0), vd, ptr(y0), B, k, seed, offset, row0,
-                                       ptr(chain_v), ptr(chain_y), C.byref(cws), int(fuse), lr, factor, batch_size,
-                                       sparse, current_stream()), "qbm_rbm_cd_step")
+        own_ws = ws is None
+        if own_ws:   # scratch reused from step to step (stream-ordered), like the discriminative step's
+            if len(self._pending) >= self.kPendingMax:   # between two steps: every recorded step is complete
+                self.check_chain_status()
+            ws = self._cd_workspace_cached(P, B)
+        cws = ws[6] if len(ws) > 6 else CdWorkspace(*(ptr(t) for t in ws[:6]))
+        check(self.lib.qbm_rbm_cd_step(C.byref(P.struct()), C.byref(G.struct(with_count=with_count)), ptr(v0), vd, ptr(y0), B, k,
+                                       seed, offset, row0, ptr(chain_v), ptr(chain_y), C.byref(cws), int(fuse), lr, factor,
+                                       batch_size, sparse, current_stream()), "qbm_rbm_cd_step")
+        if own_ws and ws[5] is not None and self._may_fuse(k, vd):
+            # the one-launch chain may have run: keep what it takes to repeat the step on the launch-per-phase path, until the
+            # next look at the status word (check_chain_status: end of an epoch, or every kPendingMax steps)
+            args = (P, G, v0, y0, k, seed, offset, row0, chain_v, chain_y, fuse, lr, factor, batch_size, sparse)
+            self._pending.append((int(offset) & 0xFFFFFFFF, replay if replay is not None else
+                                  (lambda: self.cd_step(*args, with_count=with_count))))
         if chain_v is not None:   # PCD: the k-th iteration wrote straight into the chains
             return (ws[0], ws[1], chain_v, chain_y, ws[4])
+        return ws[:6]
+
+    kPendingMax = 64    # steps between two looks at the fused chain's status word (each look synchronises the stream)
+    kWorkspaces = 8     # cached CD workspaces (one per minibatch shape: the full minibatch and a short last one)
+
+    def _may_fuse(self, k, v_dtype):
+        """Could qbm_rbm_cd_step have taken the one-launch chain for this call?  Conservative (the C side decides from the
+        shape as well) and independent of the row count, so that the ranks of a data-parallel group -- whose shards of a short
+        last minibatch differ -- record the same steps and look at the status word at the same steps."""
+        mode = int(self.lib.qbm_rbm_fused_chain_mode(-1))   # process-wide switch: asked, not cached
+        return v_dtype == QBM_U8 and (mode == 2 or (mode == 1 and k >= 2))
+
+    def _sync_buffer(self):
+        """ONE state buffer of the fused chain kernel per HipRbmOps (= per stream of work): it outlives the workspaces, which
+        are re-made when the minibatch shape changes (a short last minibatch), so a status word set in any step of an epoch
+        is still there when check_chain_status looks (a per-workspace buffer was dropped with its
+        workspace)."""
+        if self._sync is None:
+            self._sync = torch.zeros(_lib.QBM_CD_SYNC_WORDS, dtype=torch.int32, device=self.device)
+        return self._sync
+
+    def _cd_workspace_cached(self, P: ParamSet, B):
+        key = (B, P.V, P.H, P.C)
+        ws = self._cd_wss.get(key)
+        if ws is None:
+            if len(self._cd_wss) >= self.kWorkspaces:
+                self._cd_wss.pop(next(iter(self._cd_wss)))
+            t = self.cd_workspace(P, B, fused=False)[:5] + (self._sync_buffer(),)
+            ws = self._cd_wss[key] = t + (CdWorkspace(*(ptr(x) for x in t)),)
+        self._cd_ws = (key, ws)
         return ws
 
     def cd_workspace(self, P: ParamSet, B, fused=True):
@@ -227,24 +284,58 @@ class HipRbmOps:
         -> previous mode (no argument: query).  Process-wide (include/qbm_hip.h: qbm_rbm_fused_chain_mode)."""
         return int(self.lib.qbm_rbm_fused_chain_mode(int(mode)))
 
-    def check_chain_status(self, ws=None):
-        """Raise if a fused chain launch that used this workspace (default: the one cd_step keeps) gave up
-        (include/qbm_hip.h: qbm_rbm_cd_workspace.sync).  Synchronises; call it where the host synchronises anyway (end of an
-        epoch, before results are read)."""
-        if ws is None:
-            ws = self._cd_ws[1] if getattr(self, "_cd_ws", None) is not None else ()
-        if len(ws) > 5 and ws[5] is not None:
-            st = int(ws[5][512].item())
-            if st != 0:
-                raise _lib.QbmHipError(
-                    f"fused Gibbs chain kernel gave up (status {st}: " + {1: "a barrier between phases timed out", 2: "the workgroups of "
-                    "a row block were not placed on one XCD"}.get(st, "unknown") + "): the results of that step are invalid; "
-                    "set QBM_FUSED_CHAIN=0 to use one launch per phase")
+    _STATUS_TEXT = {1: "a barrier between phases timed out", 2: "the workgroups of a row block were not placed on one XCD"}
 
-    def update(self, P: ParamSet, G: GradSet, lr, factor, batch_size, sparse, with_gb=True):
-        ps, gs = P.struct(), G.struct(with_gb=with_gb)
-        check(self.lib.qbm_rbm_update(C.byref(ps), C.byref(gs), lr, factor, batch_size, sparse, current_stream()),
-              "qbm_rbm_update")
+    def check_chain_status(self, ws=None):
+        """Look at the status word of the fused chain kernel (include/qbm_hip.h: qbm_rbm_cd_workspace.sync).  Synchronises;
+        train_rbm calls it at the end of every epoch, cd_step every kPendingMax steps.
+        ws given (a caller-owned workspace): raise if a launch on it gave up.
+        ws None (the workspaces cd_step keeps): a launch that gave up has changed NOTHING -- the gradient launch behind it and
+        every later chain / gradient launch on the buffer were no-ops (FAIL-SAFE in the header) -- so the steps since then are
+        repeated here on the launch-per-phase path (same draws, same bits), the process stays on that path
+        (qbm_rbm_fused_chain_mode(0)) and a RuntimeWarning says so."""
+        if ws is not None:
+            if len(ws) > 5 and ws[5] is not None:
+                st = int(ws[5][512].item())
+                if st != 0:
+                    raise _lib.QbmHipError(
+                        f"fused Gibbs chain kernel gave up (status {st}: {self._STATUS_TEXT.get(st, 'unknown')}): the step did not "
+                        "reach the parameters; re-zero the workspace's sync buffer and repeat it with QBM_FUSED_CHAIN=0 "
+                        "(one launch per phase)")
+            return
+        pending, self._pending = self._pending, []
+        if self._sync is None or not pending:
+            return
+        st, off_lo = (int(x) & 0xFFFFFFFF for x in self._sync[512:514].tolist())   # one synchronising copy
+        if self.status_agree is not None:   # data-parallel group: every rank repeats from the first step ANY rank lost
+            st, off_lo = self.status_agree(st, off_lo)
+        if st == 0:
+            return
+        import warnings
+
+        first = next((i for i, (o, _) in enumerate(pending) if o == (off_lo & 0xFFFFFFFF)), None)
+        if first is None:
+            raise _lib.QbmHipError(
+                f"fused Gibbs chain kernel gave up (status {st}: {self._STATUS_TEXT.get(st, 'unknown')}) in a step this object "
+                "no longer holds: the steps since then did not reach the parameters; set QBM_FUSED_CHAIN=0 and repeat them")
+        self.fused_chain_mode(0)
+        self._sync.zero_()
+        warnings.warn(f"fused Gibbs chain kernel gave up (status {st}: {self._STATUS_TEXT.get(st, 'unknown')}); nothing was "
+                      f"written since. Repeating {len(pending) - first} step(s) with one launch per phase (same bits) and "
+                      "staying on that path (qbm_rbm_fused_chain_mode(0)).", RuntimeWarning)
+        for _, fn in pending[first:]:
+            fn()
+
+    def update(self, P: ParamSet, G: GradSet, lr, factor, batch_size, sparse, with_gb=True, count_dev=None, guard_chain=False):
+        """count_dev: 1-float device tensor holding the batch size (the all-reduced G.count of the data-parallel step: no host
+        round trip); guard_chain: no-op while the fused chain's status word is set (the step is repeated by
+        check_chain_status)."""
+        status = None
+        if guard_chain and self._sync is not None:
+            status = C.c_void_p(self._sync.data_ptr() + 4 * 512)
+        check(self.lib.qbm_rbm_update_dev(C.byref(P.struct()), C.byref(G.struct(with_gb=with_gb)), lr, factor,
+                                          float(batch_size) if count_dev is None else 1.0, ptr(count_dev), sparse, status,
+                                          current_stream()), "qbm_rbm_update_dev")
 
     def two_phase_grad(self, V, H, Cn, A0, Y0, P0, A1, Y1, P1, G: GradSet):
         A0, d0 = _state(A0, self.device)

@@ -127,7 +127,11 @@ class OracleRbmOps:
         if gb is not None:
             G.gb.copy_(torch.from_numpy(gb))
 
-    def update(self, P, G, lr, factor, batch_size, sparse, with_gb=True):
+    def update(self, P, G, lr, factor, batch_size, sparse, with_gb=True, count_dev=None, guard_chain=False):
+        if count_dev is not None:      # qbm_rbm_update_dev: the batch size is read from the (all-reduced) row-count slot
+            batch_size = float(count_dev.reshape(-1)[0])
+            if not (batch_size > 0.0) or batch_size > 3.0e38:
+                return
         W, b, d, U, c = self._P(P)
         orc.rbm_update(W, b, d, U, c, _np(G.gW), _np(G.gb) if with_gb else None, _np(G.gd), _np(G.gU), _np(G.gc),
                        lr, factor, batch_size, sparse)
@@ -141,7 +145,9 @@ class OracleRbmOps:
         for t in (G.gW, G.gd, G.gU, G.gc) + ((G.gb,) if with_gb else ()):
             t.zero_()
 
-    def disc_step(self, P, G, x, labels, apply_update, fuse, lr, factor, batch_size, sparse):
+    def disc_step(self, P, G, x, labels, apply_update, fuse, lr, factor, batch_size, sparse, with_count=False):
+        if with_count:                 # qbm_rbm_grads.n_rows: the gradient launch stores its row count
+            G.count.fill_(float(len(x)))
         if len(x) == 0:
             self._zero(G, with_gb=False)
             return torch.empty(0, P.C)
@@ -153,7 +159,9 @@ class OracleRbmOps:
         return torch.from_numpy(p)
 
     def cd_step(self, P, G, v0, y0, k, seed, offset, row0, chain_v, chain_y, fuse, lr, factor, batch_size, sparse,
-                ws=None):
+                ws=None, with_count=False, replay=None):
+        if with_count:
+            G.count.fill_(float(len(v0)))
         if len(v0) == 0:
             self._zero(G)
             return tuple(torch.empty(0, n) for n in (P.H, P.H, P.V, P.C, P.H))

@@ -167,7 +167,9 @@ def test_against_reference_golden(ops, name):
         assert np.max(np.abs(cpu(p) - g[f"pyx_{tag}"])) <= 2e-4
 
 
-@pytest.mark.parametrize("V,H,C,B", SHAPES + [(100, 70, 15, 300), (64, 40, 5, 515)])  # + batch > one 256-row tile
+# + batch > one 256-row tile; + the benchmark shape at B = 1024: several panels per K chain of the gradient (uint8 inputs:
+# the phase-parallel 512-thread kernel)
+@pytest.mark.parametrize("V,H,C,B", SHAPES + [(100, 70, 15, 300), (64, 40, 5, 515), (784, 512, 10, 1024)])
 def test_discriminative_step_bitwise(ops, oracle, V, H, C, B):
     from qbm_image_classification_amd.rbm_ops import GradSet
 
@@ -194,7 +196,12 @@ def test_discriminative_step_bitwise(ops, oracle, V, H, C, B):
 
 
 @pytest.mark.parametrize("V,H,C,B,k,pcd", [(16, 8, 2, 6, 1, False), (13, 9, 3, 5, 2, True), (784, 128, 2, 128, 1, False),
-                                           (784, 512, 10, 256, 1, False), (784, 512, 10, 64, 3, True)])
+                                           (784, 512, 10, 256, 1, False), (784, 512, 10, 64, 3, True),
+                                           # more than one panel per K chain of the gradient (the panel is capped at 64 k, a
+                                           # chain of B = 2048 rows is 512 k long): the multi-panel loop of the 512-thread
+                                           # phase-parallel k_grad behind the B = 2048 numbers of DESIGN.md; B = 544: a
+                                           # ragged last panel, persistent chains
+                                           (784, 512, 10, 2048, 1, False), (784, 512, 10, 544, 2, True)])
 def test_cd_step_bitwise(ops, oracle, V, H, C, B, k, pcd):
     from qbm_image_classification_amd.rbm_ops import GradSet
 
@@ -205,13 +212,14 @@ def test_cd_step_bitwise(ops, oracle, V, H, C, B, k, pcd):
     ph0, vk, yk, phk = oracle.rbm_cd_chain(v_bin, y1h, W, b, d, U, c, k, seed, off, row0,
                                            None if not pcd else cv[0], None if not pcd else cv[1])
     gW, gb, gd, gU, gc = oracle.rbm_two_phase_grad(v_bin, y1h, ph0, vk, yk, phk)
-    for fuse in (False, True):
+    # the visible data go in as fp32 (what the reference holds) or as uint8 {0,1}: same bits out; uint8 data take the
+    # phase-parallel gradient kernel, with the update fused and with the gradients materialised (the data-parallel form)
+    for fuse, as_u8 in ((False, False), (True, True), (False, True)):
         P = P_of(ops, W, b, d, U, c)
         G = GradSet(V, H, C, ops.device)
         chain_v = dev(ops, np.roll(v_bin, 1, axis=0).astype(np.uint8)) if pcd else None
         chain_y = dev(ops, np.roll(y1h, 1, axis=0)) if pcd else None
-        # the visible data go in as fp32 (what the reference holds) or as uint8 {0,1}: same bits out
-        v0_in = dev(ops, v_bin) if not fuse else dev(ops, v_bin.astype(np.uint8))
+        v0_in = dev(ops, v_bin.astype(np.uint8)) if as_u8 else dev(ops, v_bin)
         ws = ops.cd_step(P, G, v0_in, dev(ops, y1h), k, seed, off, row0, chain_v, chain_y, fuse, 0.05, 1.0,
                          float(B), 0.0)
         assert_bitwise(ws[0], ph0, "p(h0)")
