@@ -137,6 +137,8 @@ def test_training_from_device_dataset_equals_manual_batches(dops):
         manual.append([(torch.from_numpy(xb[perm[i:i + 16]]), torch.from_numpy(y[perm[i:i + 16]])) for i in range(0, 70, 16)])
 
     class Loader:
+        batch_size = 16   # like torch's DataLoader: the nominal minibatch, by which the Philox row counter advances per step
+
         def __init__(self):
             self.ep = 0
 
