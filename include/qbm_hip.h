@@ -173,6 +173,16 @@ typedef struct {
                      * same bits (rbm_ops.HipRbmOps.check_chain_status does exactly that).  NULL = always the
                      * launch-per-phase path.  One buffer per stream of concurrent work; workspaces of different
                      * shapes on one stream may share it. */
+    /* The training loop's monitor, qbm_rbm_cd_step only (all five set, or mon_labels NULL = off): the step also evaluates
+     * p(y|x0) of its minibatch under the parameters BEFORE its update -- what discriminative_training reports
+     * (src/ClassificationRBM.py:108, :142) -- from v0.W + d, which the positive-phase launch stores on the way (one more
+     * kernel, no further contraction), and books the minibatch means of the two loss terms into mon_loss_acc
+     * (qbm_rbm_disc_workspace.rowloss / loss_acc: same definitions). */
+    const int32_t* mon_labels; /* [B] */
+    float* mon_pre;            /* [B,H] */
+    float* mon_p;              /* [B,C] p(y|x0) */
+    float* mon_rowloss;        /* [B,2] */
+    double* mon_loss_acc;      /* [2] */
 } qbm_rbm_cd_workspace;
 #define QBM_CD_SYNC_WORDS 576
 
@@ -205,16 +215,20 @@ QBM_API int qbm_rbm_cd_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, con
 
 /* caller-owned scratch of one discriminative step */
 typedef struct {
-    float* pre;    /* [B,H] */
-    float* pos;    /* [B,H] */
-    float* neg;    /* [B,H] */
-    float* onehot; /* [B,C] */
-    float* cls_neg; /* [C,H] sum_i sigma(pre_i + U_c) p(c|x_i), the subtrahend of the class-weight gradient */
+    float* pre;       /* [B,H] x.W + d */
+    float* diff;      /* [B,H] pos - neg: o_{y_i} - sum_c o_c p(c|x_i), src/ClassificationRBM.py:113-115, :124-126, :134 */
+    float* rowloss;   /* [B,2] per row: CrossEntropyLoss ON THE PROBABILITIES, log(sum_c exp(p_c)) - p_label (:142, the reference's
+                       * quirk), and -log(p_label + 1e-8) (:188-190) */
+    double* loss_acc; /* optional, [2]: += the minibatch means (fp32: quartered chain over the rows, / B) of the two columns of
+                       * rowloss, i.e. the reference's `epoch_error += batch_error.item()` and `epoch_nll += nll.item()`
+                       * (:187, :191) on the device -- the training loop reads them once per epoch */
 } qbm_rbm_disc_workspace;
 
-/* ClassificationRBM.discriminative_training, src/ClassificationRBM.py:101-146 without the host-side
- * loss: p_y[B,C] = p(y|x) before the update (returned third by the reference), neg_free_energy[B,C]
- * optional.  fuse_update as above; apply_update == 0 leaves the parameters untouched (gradients only).
+/* ClassificationRBM.discriminative_training, src/ClassificationRBM.py:101-146: p_y[B,C] = p(y|x) before the update (returned
+ * third by the reference), neg_free_energy[B,C] optional.  Three launches: x.W + d; per row -F, p(y|x), pos - neg and the
+ * loss terms; then ONE contraction over the batch gW = x^T.(pos - neg) (the reference forms x^T.pos and x^T.neg by
+ * broadcasting and subtracts: the same sum up to fp32 rounding) with gd, gU, gc and the loss bookkeeping riding along.
+ * fuse_update as above; apply_update == 0 leaves the parameters untouched (gradients only).
  * B == 0: the non-NULL blocks of G are zeroed, the parameters are left alone. */
 QBM_API int qbm_rbm_disc_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const float* x,
                               const int32_t* labels, int B, float* p_y, float* neg_free_energy,
@@ -222,7 +236,7 @@ QBM_API int qbm_rbm_disc_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, c
                               float factor, float batch_size, float sparse_constant, void* stream);
 
 /* The same with x[B,V] as fp32 or as uint8 {0,1} (x_dtype): binary inputs as bytes take the uint8 kernels (a quarter of the
- * operand bytes; the two phases of the gradient run side by side).  Same values as the fp32 input 0.0 / 1.0. */
+ * operand bytes).  Same values as the fp32 input 0.0 / 1.0. */
 QBM_API int qbm_rbm_disc_step_ex(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void* x, int x_dtype,
                                  const int32_t* labels, int B, float* p_y, float* neg_free_energy,
                                  const qbm_rbm_disc_workspace* ws, int apply_update, int fuse_update, float lr,

@@ -255,8 +255,10 @@ def rbm_two_phase_grad(A0, Y0, P0, A1, Y1, P1):
     return gW, gb, gd, gU, gc
 
 
-def rbm_disc_grad(x, labels, W, d, U, c):
-    """-> (gW, gd, gU, gc, p(y|x), negF); gb is identically zero in the reference (:138)."""
+def rbm_disc_grad(x, labels, W, d, U, c, with_loss=False):
+    """-> (gW, gd, gU, gc, p(y|x), negF); gb is identically zero in the reference (:138).
+    with_loss: additionally (rowloss [B,2], batchloss [2]): CrossEntropyLoss-on-probabilities and -log(p_y + 1e-8) per row
+    and as batch means (src/ClassificationRBM.py:142, :188-191)."""
     x, W, d, U, c = _f32(x), _f32(W), _f32(d), _f32(U), _f32(c)
     labels = np.ascontiguousarray(labels, dtype=np.int32)
     B, V = x.shape
@@ -268,11 +270,30 @@ def rbm_disc_grad(x, labels, W, d, U, c):
     gc = np.empty(Cn, np.float32)
     p = np.empty((B, Cn), np.float32)
     nf = np.empty((B, Cn), np.float32)
+    rl = np.empty((B, 2), np.float32)
+    bl = np.empty(2, np.float32)
     f = lib().orc_rbm_disc_grad
-    f.argtypes = [_f32p, _i32p, _f32p, _f32p, _f32p, _f32p] + [C.c_int] * 4 + [_f32p] * 6
+    f.argtypes = [_f32p, _i32p, _f32p, _f32p, _f32p, _f32p] + [C.c_int] * 4 + [_f32p] * 8
     f.restype = None
-    f(x, labels, W, d, U, c, B, V, H, Cn, gW, gd, gU, gc, p, nf)
+    f(x, labels, W, d, U, c, B, V, H, Cn, gW, gd, gU, gc, p, nf, rl, bl)
+    if with_loss:
+        return gW, gd, gU, gc, p, nf, rl, bl
     return gW, gd, gU, gc, p, nf
+
+
+def rbm_class_loss(p, labels):
+    """-> (rowloss [B,2], batchloss [2]): per row CrossEntropyLoss ON THE PROBABILITIES (src/ClassificationRBM.py:142) and
+    -log(p_y + 1e-8) (:188-190), and their batch means (quartered chain over the rows, / B)."""
+    p = _f32(p)
+    labels = np.ascontiguousarray(labels, dtype=np.int32)
+    B, Cn = p.shape
+    rl = np.empty((B, 2), np.float32)
+    bl = np.empty(2, np.float32)
+    f = lib().orc_rbm_class_loss
+    f.argtypes = [_f32p, _i32p, C.c_int, C.c_int, _f32p, _f32p]
+    f.restype = None
+    f(p, labels, B, Cn, rl, bl)
+    return rl, bl
 
 
 def rbm_cd_chain(v0, y0, W, b, d, U, c, k, seed=0, offset=0, row0=0, chain_v=None, chain_y=None):

@@ -29,15 +29,17 @@ class RbmGrads(C.Structure):
 
 class CdWorkspace(C.Structure):
     _fields_ = [("ph0", C.c_void_p), ("h", C.c_void_p), ("vk", C.c_void_p), ("yk", C.c_void_p), ("phk", C.c_void_p),
-                ("sync", C.c_void_p)]   # state of the fused chain kernel (QBM_CD_SYNC_WORDS uint32, zeroed once) or None
+                ("sync", C.c_void_p),   # state of the fused chain kernel (QBM_CD_SYNC_WORDS uint32, zeroed once) or None
+                # the training loop's monitor (include/qbm_hip.h): labels, x.W + d, p(y|x), per-row loss terms, running sums
+                ("mon_labels", C.c_void_p), ("mon_pre", C.c_void_p), ("mon_p", C.c_void_p), ("mon_rowloss", C.c_void_p),
+                ("mon_loss_acc", C.c_void_p)]
 
 
 QBM_CD_SYNC_WORDS = 576
 
 
 class DiscWorkspace(C.Structure):
-    _fields_ = [("pre", C.c_void_p), ("pos", C.c_void_p), ("neg", C.c_void_p), ("onehot", C.c_void_p),
-                ("cls_neg", C.c_void_p)]
+    _fields_ = [("pre", C.c_void_p), ("diff", C.c_void_p), ("rowloss", C.c_void_p), ("loss_acc", C.c_void_p)]
 
 
 _p = C.c_void_p

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libqbm_hip.so")
 SOURCES = ["rbm_kernels.hip", "qubo_kernels.hip", "data_kernels.hip", "coreset_kernels.hip"]
-HEADERS = ["qbm_device.hip.h", "strip_mma.hip.h", os.path.join("..", "..", "include", "qbm_hip.h")]
+HEADERS = ["qbm_device.hip.h", "strip_mma.hip.h", "qbm_host.hpp", os.path.join("..", "..", "include", "qbm_hip.h")]
 # -ffp-contract=off: the numerical contract places every FMA explicitly
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]

@@ -175,20 +175,27 @@ class ClassificationRBM:
 
         return dist.get_rank() * int(self._rank_rows if self._rank_rows else local_rows)
 
-    def discriminative_training(self, input_data, class_label, factor=1):
-        """src/ClassificationRBM.py:101-146 -> (error, predicted, class_probabilities)"""
+    def _disc_step(self, input_data, class_label, factor, loss_acc=None, p_out=None):
+        """One discriminative pass + update (single GPU: everything in three launches; data parallel: + the all-reduce and
+        the update launch) -> p(y|x).  loss_acc: float64 [2] device tensor the step adds its two loss terms to."""
         batch_size = input_data.size(0)
         P = self._params()
         self.visible_bias_grad = 0  # :138
         lr, sp = float(self.learning_rate), float(self.sparse_constant)
         if self.data_parallel:
             p = self.ops.disc_step(P, self._grads, input_data, class_label, False, False, lr, float(factor),
-                                   float(batch_size), sp, with_count=True)
+                                   float(batch_size), sp, with_count=True, loss_acc=loss_acc, p_out=p_out)
             self._allreduce_grads()
             self.ops.update(P, self._grads, lr, float(factor), 0.0, sp, with_gb=False, count_dev=self._grads.count)
         else:
             p = self.ops.disc_step(P, self._grads, input_data, class_label, True, not self.keep_grads, lr,
-                                   float(factor), float(batch_size), sp)
+                                   float(factor), float(batch_size), sp, loss_acc=loss_acc, p_out=p_out)
+        return p
+
+    def discriminative_training(self, input_data, class_label, factor=1):
+        """src/ClassificationRBM.py:101-146 -> (error, predicted, class_probabilities)"""
+        batch_size = input_data.size(0)
+        p = self._disc_step(input_data, class_label, factor)
         labels_dev = torch.as_tensor(class_label).to(self.device).long()
         if batch_size == 0:   # an empty shard of a short last minibatch (data-parallel ranks only)
             return torch.zeros((), device=self.device), labels_dev, p
@@ -196,14 +203,25 @@ class ClassificationRBM:
         _, predicted = torch.max(p, 1)
         return error, predicted, p
 
-    def contrastive_divergence_training(self, input_data, class_label, factor=1):
+    def contrastive_divergence_training(self, input_data, class_label, factor=1, *, onehot=None, loss_acc=None):
         """CD-k (or PCD when persistent=True) generative step, SURVEY.md 8.A-7:
         dW = v0^T p(h0) - vk^T p(hk), db = sum(v0 - vk), dd = sum(p(h0) - p(hk)), dU = y0^T p(h0) - yk^T p(hk),
-        dc = sum(y0 - yk); update rule of src/ClassificationRBM.py:88-99."""
+        dc = sum(y0 - yk); update rule of src/ClassificationRBM.py:88-99.
+        onehot: the labels as fp32 one-hot rows if the caller has them (DeviceDataset delivers them with the gather);
+        loss_acc: float64 [2] device tensor -- the step then also evaluates p(y|x) of its minibatch under the parameters
+        BEFORE its update (what discriminative_training reports) and adds the two loss terms of train_rbm's bookkeeping."""
         batch_size = input_data.size(0)
         P = self._params()
-        labels_dev = torch.as_tensor(class_label).to(self.device).long()
-        y0 = torch.nn.functional.one_hot(labels_dev, num_classes=self.num_classes).float()
+        if onehot is None:
+            labels_dev = torch.as_tensor(class_label).to(self.device).long()
+            onehot = torch.nn.functional.one_hot(labels_dev, num_classes=self.num_classes).float()
+        y0 = onehot
+        monitor = None
+        if loss_acc is not None:
+            lab32 = torch.as_tensor(class_label)
+            if lab32.dtype != torch.int32 or lab32.device != self.device:
+                lab32 = lab32.to(self.device, torch.int32)
+            monitor = (lab32.contiguous(), loss_acc)
         v0 = torch.as_tensor(input_data)
         # uint8 {0,1} minibatches (DeviceDataset with binary storage) stay bytes: the Gibbs kernels read them as such
         v0 = v0.to(self.device) if v0.dtype == torch.uint8 else v0.to(self.device, torch.float32)
@@ -225,16 +243,17 @@ class ClassificationRBM:
         # its one-launch chain have given up (its gradient and update launches were then no-ops)
         if self.data_parallel:
             def step():
-                self.ops.cd_step(P, G, v0, y0, k, seed, offset, row0, cv, cy, False, lr, f, bs, sp, with_count=True, replay=step)
+                self.ops.cd_step(P, G, v0, y0, k, seed, offset, row0, cv, cy, False, lr, f, bs, sp, with_count=True, replay=step,
+                                 monitor=monitor)
                 self._allreduce_grads()
                 self.ops.update(P, G, lr, f, 0.0, sp, count_dev=G.count)   # global batch size read on the device
         elif self.keep_grads:
             def step():
-                self.ops.cd_step(P, G, v0, y0, k, seed, offset, row0, cv, cy, False, lr, f, bs, sp, replay=step)
+                self.ops.cd_step(P, G, v0, y0, k, seed, offset, row0, cv, cy, False, lr, f, bs, sp, replay=step, monitor=monitor)
                 self.ops.update(P, G, lr, f, bs, sp, guard_chain=True)
         else:  # every update fused into the gradient launch
             def step():
-                self.ops.cd_step(P, G, v0, y0, k, seed, offset, row0, cv, cy, True, lr, f, bs, sp, replay=step)
+                self.ops.cd_step(P, G, v0, y0, k, seed, offset, row0, cv, cy, True, lr, f, bs, sp, replay=step, monitor=monitor)
         step()
         # Philox rows advance by the NOMINAL global minibatch (the loader's batch_size x ranks; a short last minibatch
         # included): known on the host of every rank without asking the device for the all-reduced row count
@@ -259,40 +278,43 @@ class ClassificationRBM:
         nll_list = []
         best_validation_model = None
         self._rank_rows = getattr(train_loader, 'batch_size', None)   # nominal rows per rank (Philox row offsets)
+        if method not in ('discriminative', 'generative', 'hybrid'):
+            raise NotImplementedError(method)
+        gen_factor = generative_factor if generative_factor is not None else (1 if method == 'generative' else 0.01)
+        # a DeviceDataset hands out device tensors as the kernels take them (uint8 / fp32 rows, int32 labels, one-hot rows
+        # from the same gather launch): no conversion launches per step
+        resident = hasattr(train_loader, 'batches') and hasattr(train_loader, 'epoch')
+        sums = torch.zeros(2, dtype=torch.float64, device=self.device)
         for epoch in range(epochs):
-            # the running sums live on the device as float64 scalars: the same IEEE double additions, in the same
-            # order, as the reference's `epoch_error += batch_error.item()` -- without a host sync per step
-            epoch_error_t = torch.zeros((), dtype=torch.float64, device=self.device)
-            epoch_nll_t = torch.zeros((), dtype=torch.float64, device=self.device)
-            for batch, labels in train_loader:
-                batch = batch.view(len(batch), self.num_visible)  # flatten input data (:173)
-                # uint8 {0,1} minibatches (device_data.DeviceDataset) stay bytes: the Gibbs kernels read them as such
-                batch = batch.to(self.device) if batch.dtype == torch.uint8 else batch.to(self.device, torch.float32)
-                labels = labels.to(self.device)
+            # The two running sums of the epoch (:187 `epoch_error += batch_error.item()`, :191 `epoch_nll += nll.item()`)
+            # live ON THE DEVICE as float64: the gradient launch of every step adds its minibatch's terms (per row
+            # CrossEntropyLoss on the probabilities, :142, and -log(p_y + 1e-8), :188-190; fp32 batch means, then the same
+            # IEEE double additions in the same order as the reference's Python floats) -- no launch, no host sync per step.
+            sums.zero_()
+            if resident:
+                batches = train_loader.batches(want_onehot=method != 'discriminative')
+            else:
+                batches = ((b, l, None) for b, l in train_loader)
+            for batch, labels, onehot in batches:
+                if not resident:
+                    batch = batch.view(len(batch), self.num_visible)  # flatten input data (:173)
+                    # uint8 {0,1} minibatches stay bytes: the kernels read them as such
+                    batch = batch.to(self.device) if batch.dtype == torch.uint8 else batch.to(self.device, torch.float32)
+                    labels = labels.to(self.device, torch.int32)
                 if method == 'discriminative':
-                    batch_error, _, class_probs = self.discriminative_training(batch, labels, discriminative_factor)
+                    self._disc_step(batch, labels, discriminative_factor, sums, False)
                 elif method == 'generative':
-                    self.contrastive_divergence_training(batch, labels, 1 if generative_factor is None else generative_factor)
-                    class_probs = self.sample_class_given_x(batch)
-                    batch_error = self.loss(class_probs, labels.long())
-                elif method == 'hybrid':
-                    # Larochelle & Bengio hybrid objective: discriminative step + generative_factor * CD-k step
-                    batch_error, _, class_probs = self.discriminative_training(batch, labels, discriminative_factor)
-                    self.contrastive_divergence_training(batch, labels, 0.01 if generative_factor is None else generative_factor)
+                    # p(y|x) is monitored under the parameters BEFORE the step's update, like the discriminative rule's report
+                    self.contrastive_divergence_training(batch, labels, gen_factor, onehot=onehot, loss_acc=sums)
                 else:
-                    raise NotImplementedError(method)
-
-                epoch_error_t += batch_error.detach().double()
-                if batch.size(0) == 0:   # empty shard of a short last minibatch (data-parallel ranks only)
-                    continue
-                # NLL of the batch (:188-191)
-                log_probs = torch.log(class_probs + 1e-8)
-                nll = -log_probs[torch.arange(batch.size(0), device=self.device), labels.long()]
-                epoch_nll_t += nll.mean().double()
-
-            epoch_error, epoch_nll = epoch_error_t.item(), epoch_nll_t.item()
+                    # Larochelle & Bengio hybrid objective: discriminative step + generative_factor * CD-k step
+                    self._disc_step(batch, labels, discriminative_factor, sums, False)
+                    self.contrastive_divergence_training(batch, labels, gen_factor, onehot=onehot)
+            if resident:
+                train_loader.epoch += 1
             if hasattr(self.ops, "check_chain_status"):
-                self.ops.check_chain_status()   # the one-launch Gibbs chain reports a failed placement check here (never silently)
+                self.ops.check_chain_status()   # the one-launch Gibbs chain: a launch that gave up is repeated here (never silently lost)
+            epoch_error, epoch_nll = sums.tolist()   # the epoch's one synchronisation
             loss_list.append(epoch_error / len(train_loader))
             nll_list.append(epoch_nll / len(train_loader))
 

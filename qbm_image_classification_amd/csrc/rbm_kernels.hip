@@ -87,6 +87,8 @@ struct HiddenArgs {
     uint32_t row0;
     bool epiDma;   // the epilogue operands (bias tile, U tile, y rows) of a wavefront come by LDS-DMA transfers
     int ldsCls;    // byte offset of the per-wavefront scratch of those transfers (2 KiB each) in the dynamic LDS
+    float* pre;    // [B,H] or null   MODE 0 only: v.W + d WITHOUT the class term (what MODE 1 delivers), for the training
+                   // loop's p(y|x) monitor (qbm_rbm_cd_workspace.mon_*): one more store instead of one more contraction
 };
 
 // 8 wavefronts (512 threads): wavefront q contracts chain q of the 8 the K = V terms are cut into ([Q] with NQ = 8), two
@@ -214,6 +216,7 @@ __device__ __forceinline__ void hidden_body(const HiddenArgs& a, int ms, int ns,
     if (o.valid(0) && row < a.B && j0 < a.H) {
         float x = o.sum[0].x + dv, pv, hv = 0.f;
         if (MODE == 0) {
+            if (a.pre) a.pre[(long)row * a.H + j0] = x;
             if (a.y) x = x + cls;
             pv = det_sigmoid(x);
             hv = (pv > uu) ? 1.f : 0.f;
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(64 * H_NQ) void k_hidden(HiddenArgs a)
     // every kernel argument in ONE round trip to the (cold) scalar cache: the compiler otherwise fetches them where they
     // are first used, one dependent s_load latency after the other in front of the first operand transfer
     asm volatile("" ::"s"(a.v), "s"(a.y), "s"(a.W), "s"(a.d), "s"(a.U), "s"(a.p), "s"(a.s), "s"(a.s8), "s"(a.B), "s"(a.V),
-                 "s"(a.H), "s"(a.C), "s"(a.KP), "s"(a.seed), "s"(a.offset), "s"(a.row0));
+                 "s"(a.H), "s"(a.C), "s"(a.KP), "s"(a.seed), "s"(a.offset), "s"(a.row0), "s"(a.pre));
     const int nM = (a.B + 16 * H_MT - 1) / (16 * H_MT), nN = (a.H + 16 * H_NT - 1) / (16 * H_NT);
     int ms, ns;
     strip_coords(nM, nN, ms, ns);
@@ -680,7 +683,7 @@ __global__ __launch_bounds__(512) void k_chain(ChainArgs a)
         if (hidden) {
             if (j < nNh) {
                 const HiddenArgs ha{vin, yin, a.W, a.d, a.U, pout, nullptr, hout, a.B, a.V, a.H, a.C, a.KPh, a.seed, off, a.row0,
-                                    true, a.ldsCls};
+                                    true, a.ldsCls, nullptr};
                 hidden_body<uint8_t, 2, 0, CM, kSc1>(ha, g, j, lds + a.ldsT, lds, w_resident);
                 w_resident = true;
             }
@@ -710,27 +713,45 @@ __global__ __launch_bounds__(512) void k_chain(ChainArgs a)
 // ---------------------------------------------------------------------------------------------
 // One workgroup per row, one wave per class (blockDim = 64 C): wave c does the wave tree [T] over j for class c,
 // the -F values meet in LDS, thread (c, d) forms exp(F_c - F_d) and thread c adds them up in d order -> p(y|x).
-// With `pos` set, the workgroup goes on to the elementwise stage of discriminative_training for its row while p is
-// still in LDS (src/ClassificationRBM.py:106-107, :113-115, :124-126):  o_c = sigma(pre + U_c);  pos = o_{label};
-// neg = sum_c o_c * p_c (mul, then add, classes ascending).
+// With `diff` set, the workgroup goes on to the elementwise stage of discriminative_training for its row while p is
+// still in LDS (src/ClassificationRBM.py:106-107, :113-115, :124-126, :134):  o_c = sigma(pre + U_c);  pos = o_{label};
+// neg = sum_c o_c * p_c (mul, then add, classes ascending);  diff = pos - neg -- and to the two scalars the training loop
+// books per row (`rowloss`): CrossEntropyLoss applied to the probabilities, log(sum_c exp(p_c)) - p_label (:142), and
+// -log(p_label + 1e-8) (:188-190).
+// All loads of a stage are issued before its arithmetic (a lane's 8 columns of a 512-unit row: a dependent L2 round trip
+// per column would otherwise be most of the kernel).
 template <int CM>
 __global__ __launch_bounds__(64 * CM) void k_free_energy(const float* __restrict__ pre, const float* __restrict__ U,
                                                          const float* __restrict__ cb, float* __restrict__ negF,
                                                          float* __restrict__ p_out, int B, int H, int C,
-                                                         const int* __restrict__ labels, float* __restrict__ pos,
-                                                         float* __restrict__ neg, float* __restrict__ onehot)
+                                                         const int* __restrict__ labels, float* __restrict__ diff,
+                                                         float* __restrict__ rowloss)
 {
     __shared__ float nf_s[CM + 1], p_s[CM + 1];
     __shared__ float e_s[CM * CM];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = class
     const int i = blockIdx.x;
+    const int lab = labels ? labels[i] : 0;
     {
         float nf = 0.f;
         const float cbv = cb[w];
         const float* prow = pre + (long)i * H;
         const float* urow = U + (long)w * H;
-        for (int j = lane; j < H; j += kWave) nf = nf + det_softplus(prow[j] + urow[j]);
+        for (int jb = 0; jb < H; jb += 8 * kWave) {   // the lane chains j = lane, lane + 64, ... ascending ([T])
+            float pv[8], uv[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int jj = min(jb + t * kWave + lane, H - 1);
+                pv[t] = prow[jj];
+                uv[t] = urow[jj];
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float sp = det_softplus(pv[t] + uv[t]);
+                nf = (jb + t * kWave + lane < H) ? nf + sp : nf;
+            }
+        }
         const float v = cbv + wave_butterfly_sum(nf);
         if (lane == 0) nf_s[w] = v;
     }
@@ -749,106 +770,34 @@ __global__ __launch_bounds__(64 * CM) void k_free_energy(const float* __restrict
         if (negF) negF[(long)i * C + c] = nf_s[c];
         if (p_out) p_out[(long)i * C + c] = pc;
     }
-    if (!pos) return;
+    if (!diff && !rowloss) return;
     __syncthreads();
-    const int lab = labels[i];
-    if (threadIdx.x < C && onehot) onehot[(long)i * C + threadIdx.x] = ((int)threadIdx.x == lab) ? 1.f : 0.f;
+    if (threadIdx.x == 0 && rowloss) {
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < CM; ++c)
+            if (c < C) se = se + det_expf(p_s[c]);
+        const float py = p_s[lab];
+        rowloss[2 * (long)i] = det_logf(se) - py;
+        rowloss[2 * (long)i + 1] = -det_logf(py + 1e-8f);
+    }
+    if (!diff) return;
     for (int j = threadIdx.x; j < H; j += blockDim.x) {
         const float pr = pre[(long)i * H + j];
+        float uv[CM];
+#pragma unroll
+        for (int c = 0; c < CM; ++c) uv[c] = U[(long)min(c, C - 1) * H + j];
         float ng = 0.f, ps = 0.f;
 #pragma unroll
         for (int c = 0; c < CM; ++c) {
             if (c < C) {
-                const float o = det_sigmoid(pr + U[(long)c * H + j]);
+                const float o = det_sigmoid(pr + uv[c]);
                 ps = (c == lab) ? o : ps;
                 ng = ng + o * p_s[c];
             }
         }
-        pos[(long)i * H + j] = ps;
-        neg[(long)i * H + j] = ng;
+        diff[(long)i * H + j] = ps - ng;
     }
-}
-
-// theta += ((factor * g) * lr) / bs, then - sparse for the biases (src/ClassificationRBM.py:88-99)
-struct StepScale { float lr, factor, bs, sparse; };
-__device__ __forceinline__ float upd_s(float th, float g, const StepScale& k, bool sparse)
-{
-    float t = k.factor * g;
-    t = t * k.lr;
-    t = t / k.bs;
-    th = th + t;
-    return sparse ? th - k.sparse : th;
-}
-
-// A-5, class-weight / class-bias part (:113-115, :125, :132, :136):
-//   gU[c,j] = (onehot^T.pos)[c,j] - sum_i o_icj p_ic      (first term: k_grad, which subtracts `usub` written here)
-//   gc[c]   = sum_i onehot_ic - sum_i p_ic
-// Batch sums are quartered chains [Q].  Workgroup = (class c, 16 hidden columns): the 256 threads evaluate the
-// products o*p of 256 batch rows x 16 columns into LDS, then thread (quarter q, column) adds its quarter's rows in
-// order.  The workgroup of columns 0..15 also does gc[c]; with `uc` / `ub` set it applies the class-bias update and
-// the gradient-free visible-bias update (:138: grad 0, sparsity constant still applied).
-__global__ __launch_bounds__(256) void k_disc_class_grad(const float* __restrict__ pre, const float* __restrict__ U,
-                                                         const float* __restrict__ p, const int* __restrict__ labels,
-                                                         float* __restrict__ usub, float* __restrict__ gU,
-                                                         float* __restrict__ gc, float* __restrict__ uc,
-                                                         float* __restrict__ ub, StepScale sc, int B, int H, int C, int V)
-{
-    __shared__ float t_s[256][17];
-    __shared__ float pc_s[256], oh_s[256];
-    __shared__ float part[4][18];
-    const int nJ = (H + 15) / 16;
-    const int c = blockIdx.x / nJ, jb = blockIdx.x % nJ;
-    const int col = threadIdx.x & 15, slot = threadIdx.x >> 4;
-    const int j = jb * 16 + col, jj = min(j, H - 1);
-    const int Kq = quarter_len(B);
-    const float u = U[(long)c * H + jj];
-    const bool chain = threadIdx.x < 64;                        // thread (q, col): the ordered sum of quarter q
-    const bool side = threadIdx.x >= 64 && threadIdx.x < 72;    // threads 64..67: sum onehot; 68..71: sum p
-    const int q = chain ? (int)(threadIdx.x >> 4) : (int)(threadIdx.x & 3);
-    const int lo = q * Kq, hi = min(B, lo + Kq);
-    float acc = 0.f;
-    for (int r0 = 0; r0 < B; r0 += 256) {
-        const int nr = min(256, B - r0);
-        float pr[16], pcv[16];
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int i = min(r0 + slot + 16 * t, B - 1);
-            pr[t] = pre[(long)i * H + jj];
-            pcv[t] = p[(long)i * C + c];
-        }
-#pragma unroll
-        for (int t = 0; t < 16; ++t) t_s[slot + 16 * t][col] = det_sigmoid(pr[t] + u) * pcv[t];
-        if (threadIdx.x < nr) {
-            pc_s[threadIdx.x] = p[(long)(r0 + threadIdx.x) * C + c];
-            oh_s[threadIdx.x] = (labels[r0 + threadIdx.x] == c) ? 1.f : 0.f;
-        }
-        __syncthreads();
-        const int a0 = max(lo, r0) - r0, a1 = min(hi, r0 + nr) - r0;
-        if (chain) {
-            for (int i = a0; i < a1; ++i) acc = __builtin_fmaf(1.0f, t_s[i][col], acc);
-        } else if (side) {
-            const float* src = threadIdx.x < 68 ? oh_s : pc_s;
-            for (int i = a0; i < a1; ++i) acc = __builtin_fmaf(1.0f, src[i], acc);
-        }
-        __syncthreads();
-    }
-    if (chain) part[q][col] = acc;
-    if (side) part[q][threadIdx.x < 68 ? 16 : 17] = acc;
-    __syncthreads();
-    if (threadIdx.x < 16 && j < H) {
-        const float ta = ((part[0][col] + part[1][col]) + part[2][col]) + part[3][col];
-        if (usub) usub[(long)c * H + j] = ta;
-        if (gU) gU[(long)c * H + j] = gU[(long)c * H + j] - ta;
-    }
-    if (jb == 0 && threadIdx.x == 0) {
-        const float t0 = ((part[0][16] + part[1][16]) + part[2][16]) + part[3][16];
-        const float t1 = ((part[0][17] + part[1][17]) + part[2][17]) + part[3][17];
-        const float g = t0 - t1;
-        if (gc) gc[c] = g;
-        if (uc) uc[c] = upd_s(uc[c], g, sc, true);
-    }
-    if (ub)
-        for (int m = blockIdx.x * 256 + threadIdx.x; m < V; m += gridDim.x * 256) ub[m] = upd_s(ub[m], 0.f, sc, true);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -893,6 +842,15 @@ struct GradArgs {
                                                  // non-zero = that launch gave up: this launch writes nothing (but n_rows)
     float* n_rows;                               // non-null: receives (float)B -- the data-parallel path all-reduces it with the
                                                  // gradients -- or -inf when `status` is set (every rank then skips the update)
+    // discriminative step (kind D workgroups, BEHIND the strips in the grid; P1 == null: one phase only)
+    int nD;                                      // workgroups of kind D: C x ceil(H / 16)
+    const float* pre; const float* Up; const float* pyx; const int* labels;   // x.W + d [B,H], U [C,H], p(y|x) [B,C], labels [B]
+    const float* rowloss;                        // [B,2] per-row loss terms (k_free_energy) or null
+    double* loss_acc;                            // non-null: [2] running sums of the per-minibatch means of the two loss terms
+    int nL;                                      // 1: one workgroup of kind L at the very end of the grid (CD step with the
+                                                 // training loop's monitor): batch means of `rowloss` -> loss_acc
+    float* dgU; float* dgc;                      // gradient outputs of kind D (null = not wanted)
+    float* duU; float* duc; float* dub;          // fused updates by kind D: class weights, class bias, visible bias (sparsity only)
 };
 
 __device__ __forceinline__ float upd(float th, float g, const GradArgs& a, bool sparse)
@@ -929,11 +887,128 @@ __device__ __forceinline__ void swap_strips(const StripOut<MT_, NT_>& mine, int 
     }
 }
 
+// Kind L (CD-k step with the training loop's monitor): the minibatch means of the two per-row loss terms -- quartered
+// chains [Q] over the rows (staged through LDS), / B -- added to the float64 running sums (src/ClassificationRBM.py:187, :191).
+__device__ __forceinline__ void loss_block(const GradArgs& a, char* lds_raw)
+{
+    float* rl = reinterpret_cast<float*>(lds_raw);   // [tile][2], then 8 partial sums
+    const int B = a.B, n = (int)blockDim.x, tid = (int)threadIdx.x;
+    float* part = rl + 2 * n;
+    const int Kq = quarter_len(B);
+    const int q = tid & 3, k = (tid >> 2) & 1;        // threads 0..7: (quarter q, column k)
+    const int lo = q * Kq, hi = min(B, lo + Kq);
+    float acc = 0.f;
+    for (int r0 = 0; r0 < B; r0 += n) {
+        const int nr = min(n, B - r0);
+        if (tid < nr) {
+            rl[2 * tid] = a.rowloss[2 * (long)(r0 + tid)];
+            rl[2 * tid + 1] = a.rowloss[2 * (long)(r0 + tid) + 1];
+        }
+        __syncthreads();
+        if (tid < 8) {
+            const int a0 = max(lo, r0) - r0, a1 = min(hi, r0 + nr) - r0;
+            for (int i = a0; i < a1; ++i) acc = __builtin_fmaf(1.0f, rl[2 * i + k], acc);
+        }
+        __syncthreads();
+    }
+    if (tid < 8) part[tid] = acc;   // part[4 k + q]
+    __syncthreads();
+    if (tid < 2) {
+        const float m = (((part[4 * tid] + part[4 * tid + 1]) + part[4 * tid + 2]) + part[4 * tid + 3]) / (float)B;
+        a.loss_acc[tid] = a.loss_acc[tid] + (double)m;
+    }
+}
+
+// Kind D (discriminative step, src/ClassificationRBM.py:113-115, :125, :132, :136, :138, :142): what depends on the
+// class index.  Workgroup (class c, 16 hidden columns), 256 threads:
+//   gU[c,j] = sum_{i: y_i = c} pos_ij - sum_i o_icj p_ic    with o_icj = sigma(pre_ij + U_cj) (pos_ij = o_icj where y_i = c)
+//   gc[c]   = sum_i onehot_ic - sum_i p_ic                  (the workgroup of columns 0..15)
+//   the two loss terms of the minibatch: batch means of `rowloss`, added to loss_acc (class 0, columns 0..15)
+// All batch sums are quartered chains [Q]: the 256 threads evaluate o for 256 rows x 16 columns into LDS, then thread
+// (quarter q, column) walks its quarter's rows in order -- fmaf(onehot, o, acc) for the first sum (bit for bit the chain of
+// the [onehot]^T.pos contraction: rows of another class enter as 0 * o), fmaf(1, o * p, acc) for the second.
+// Fused update of U, c and of the gradient-free visible bias (:138: grad 0, the sparsity constant still applies).
+__device__ __forceinline__ void disc_class_block(const GradArgs& a, int blk, char* lds_raw)
+{
+    float (*o_s)[17] = reinterpret_cast<float (*)[17]>(lds_raw);
+    float* pc_s = reinterpret_cast<float*>(lds_raw) + 256 * 17;
+    float* oh_s = pc_s + 256;
+    float* ce_s = oh_s + 256;
+    float* nl_s = ce_s + 256;
+    float (*part)[40] = reinterpret_cast<float (*)[40]>(nl_s + 256);   // [4 quarters][16 A | 16 B | onehot | p | ce | nll]
+    const int B = a.B, H = a.H, C = a.C;
+    const int nJ = (H + 15) / 16;
+    const int c = blk / nJ, jb = blk % nJ;
+    const int tid = (int)threadIdx.x;
+    const int col = tid & 15, slot = tid >> 4;
+    const int j = jb * 16 + col, jj = min(j, H - 1);
+    const int Kq = quarter_len(B);
+    const float u = a.Up[(long)c * H + jj];
+    const bool with_loss = c == 0 && jb == 0 && a.rowloss != nullptr;
+    // roles in the summation stage: threads 0..63 chain A (o * p), 64..127 chain B (onehot * o), 128..143 the four side sums
+    const int role = tid < 64 ? 0 : tid < 128 ? 1 : tid < 144 ? 2 + ((tid - 128) >> 2) : 6;
+    const int q = role <= 1 ? (tid >> 4) & 3 : tid & 3;
+    const int lo = q * Kq, hi = min(B, lo + Kq);
+    float acc = 0.f;
+    for (int r0 = 0; r0 < B; r0 += 256) {
+        const int nr = min(256, B - r0);
+        float pr[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) pr[t] = a.pre[(long)min(r0 + slot + 16 * t, B - 1) * H + jj];
+        const int ir = min(r0 + tid, B - 1);
+        const float pcv = a.pyx[(long)ir * C + c];
+        const int labv = a.labels[ir];
+        float cev = 0.f, nlv = 0.f;
+        if (with_loss) { cev = a.rowloss[2 * (long)ir]; nlv = a.rowloss[2 * (long)ir + 1]; }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) o_s[slot + 16 * t][col] = det_sigmoid(pr[t] + u);
+        pc_s[tid] = pcv;
+        oh_s[tid] = (labv == c) ? 1.f : 0.f;
+        ce_s[tid] = cev;
+        nl_s[tid] = nlv;
+        __syncthreads();
+        const int a0 = max(lo, r0) - r0, a1 = min(hi, r0 + nr) - r0;
+        if (role == 0) {
+            for (int i = a0; i < a1; ++i) acc = __builtin_fmaf(1.0f, o_s[i][col] * pc_s[i], acc);
+        } else if (role == 1) {
+            for (int i = a0; i < a1; ++i) acc = __builtin_fmaf(oh_s[i], o_s[i][col], acc);
+        } else if (role < 6) {
+            const float* src = role == 2 ? oh_s : role == 3 ? pc_s : role == 4 ? ce_s : nl_s;
+            for (int i = a0; i < a1; ++i) acc = __builtin_fmaf(1.0f, src[i], acc);
+        }
+        __syncthreads();
+    }
+    if (role == 0) part[q][col] = acc;
+    else if (role == 1) part[q][16 + col] = acc;
+    else if (role < 6) part[q][32 + role - 2] = acc;
+    __syncthreads();
+    auto qsum = [&](int k) { return ((part[0][k] + part[1][k]) + part[2][k]) + part[3][k]; };
+    if (tid < 16 && j < H) {
+        const float g = qsum(16 + col) - qsum(col);
+        const long off = (long)c * H + j;
+        if (a.dgU) a.dgU[off] = g;
+        if (a.duU) a.duU[off] = upd(a.duU[off], g, a, false);
+    }
+    if (jb == 0 && tid == 0) {
+        const float g = qsum(32) - qsum(33);
+        if (a.dgc) a.dgc[c] = g;
+        if (a.duc) a.duc[c] = upd(a.duc[c], g, a, true);
+        if (with_loss && a.loss_acc) {   // += (double)(fp32 batch mean): `epoch_error += batch_error.item()` (:187, :191)
+            a.loss_acc[0] = a.loss_acc[0] + (double)(qsum(34) / (float)B);
+            a.loss_acc[1] = a.loss_acc[1] + (double)(qsum(35) / (float)B);
+        }
+    }
+    if (a.dub)
+        for (int m = blk * 256 + tid; m < a.V; m += a.nD * 256) a.dub[m] = upd(a.dub[m], 0.f, a, true);
+}
+
 // PAR (both data operands uint8: the Gibbs states of the CD-k / PCD step): 512 threads, the phases side by side.
 // Otherwise (fp32 data: twice the staging bytes, two regions do not fit the LDS): 256 threads, phase after phase.
-template <class T0, class T1, bool FAST, bool PAR>
+// ONE (the discriminative step): phase 0 only -- gW = A0^T.P0 -- and the kind D workgroups behind the strips; 256 threads.
+template <class T0, class T1, bool FAST, bool PAR, bool ONE = false>
 __global__ __launch_bounds__(PAR ? 512 : 256) void k_grad(GradArgs a)
 {
+    static_assert(!(PAR && ONE), "the one-phase form takes the 256-thread kernel");
     constexpr int MT = G_MT, NT = G_NT;
     extern __shared__ __attribute__((aligned(16))) char lds_all[];
     QBM_STAMP(10);
@@ -962,7 +1037,9 @@ __global__ __launch_bounds__(PAR ? 512 : 256) void k_grad(GradArgs a)
         if (grp != 0) return;                    \
     } else {                                     \
         o0 = CALL0;                              \
-        o1 = CALL1;                              \
+        if constexpr (!ONE) o1 = CALL1;          \
+        else                                     \
+            for (int op = 0; op < SOT::NP; ++op) o1.sum[op] = make_float4(0.f, 0.f, 0.f, 0.f);   \
     }
     if (blk < a.nU) {  // class-weight rows and the hidden-bias row (C + 1 <= 16 rows: one row tile) x 16*NT hidden columns
         const int n0 = blk * 16 * NT;
@@ -1032,8 +1109,20 @@ __global__ __launch_bounds__(PAR ? 512 : 256) void k_grad(GradArgs a)
         }
         return;
     }
+    blk -= a.nC;   // index among the strips (and what stands behind them)
 #undef QBM_TWO_PHASES
     const int nM = (a.V + 16 * MT - 1) / (16 * MT), nN = (a.H + 16 * NT - 1) / (16 * NT);
+    if constexpr (ONE) {
+        if (blk >= nM * nN) {   // kind D workgroups stand behind the strips
+            disc_class_block(a, blk - nM * nN, lds_all);
+            return;
+        }
+    } else {
+        if (a.nL && blk == nM * nN) {   // the last workgroup of the grid (every thread of it comes here)
+            loss_block(a, lds_all);
+            return;
+        }
+    }
     int ms, ns;
     strip_coords(nM, nN, ms, ns, a.nU + a.nB + a.nC);
     const int m0 = ms * 16 * MT, n0 = ns * 16 * NT;
@@ -1088,7 +1177,11 @@ __global__ __launch_bounds__(PAR ? 512 : 256) void k_grad(GradArgs a)
         };
         QBM_STAMP(11);
         const SO o0 = strip_mma<MT, NT, FAST, FAST>(D0, P0, m0, n0, a.B, lds, a.KP, pre0);
-        const SO o1 = strip_mma<MT, NT, FAST, FAST>(D1, P1, m0, n0, a.B, lds, a.KP, NoPre{}, NoPre{}, 5);
+        SO o1;   // ONE (the discriminative step: gW = x^T.(pos - neg)): zeros, g = o0 - 0 = o0
+        if constexpr (!ONE) o1 = strip_mma<MT, NT, FAST, FAST>(D1, P1, m0, n0, a.B, lds, a.KP, NoPre{}, NoPre{}, 5);
+        else
+#pragma unroll
+            for (int op = 0; op < SO::NP; ++op) o1.sum[op] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int op = 0; op < SO::NP; ++op) finish(op, o0.sum[op], o1.sum[op], w_old[op]);
     }
@@ -1226,12 +1319,12 @@ int panel_for_nq(int K, int reserve)
 
 template <class TA>
 int launch_hidden_t(const qbm_rbm_params* P, const void* v, const float* y, int B, float* p, float* s, uint8_t* s8,
-                    int mode, uint64_t seed, uint64_t offset, uint32_t row0, hipStream_t st)
+                    int mode, uint64_t seed, uint64_t offset, uint32_t row0, hipStream_t st, float* pre_out)
 {
     constexpr int ASZ = (int)sizeof(TA), MT = H_MT, NT = H_NT, NQ = H_NQ;
     constexpr int kScratch = NQ * 1024;   // one 1 KiB transfer slot per wavefront for the epilogue operands
     HiddenArgs a{v, y, P->W, P->d, P->U, p, s, s8, B, P->V, P->H, P->C, panel_for_nq<MT, NT, ASZ, NQ>(P->V, kScratch), seed,
-                 offset, row0, false, 0};
+                 offset, row0, false, 0, mode == 0 ? pre_out : nullptr};
     // LDS-DMA path: whole 16-k pieces, 16-byte aligned units, descriptors below 2 GiB
     const bool fast = (P->V % 16 == 0) && aligned16(v) && (P->H % 4 == 0) && aligned16(P->W) &&
                       small2g((long)B * P->V, ASZ) && small2g((long)P->V * P->H, 4);
@@ -1276,10 +1369,10 @@ int launch_hidden_t(const qbm_rbm_params* P, const void* v, const float* y, int 
 }
 
 int launch_hidden(const qbm_rbm_params* P, const void* v, int v_dtype, const float* y, int B, float* p, float* s,
-                  uint8_t* s8, int mode, uint64_t seed, uint64_t offset, uint32_t row0, hipStream_t st)
+                  uint8_t* s8, int mode, uint64_t seed, uint64_t offset, uint32_t row0, hipStream_t st, float* pre_out = nullptr)
 {
-    return v_dtype == QBM_U8 ? launch_hidden_t<uint8_t>(P, v, y, B, p, s, s8, mode, seed, offset, row0, st)
-                             : launch_hidden_t<float>(P, v, y, B, p, s, s8, mode, seed, offset, row0, st);
+    return v_dtype == QBM_U8 ? launch_hidden_t<uint8_t>(P, v, y, B, p, s, s8, mode, seed, offset, row0, st, pre_out)
+                             : launch_hidden_t<float>(P, v, y, B, p, s, s8, mode, seed, offset, row0, st, pre_out);
 }
 
 // sample_visible, optionally with the class conditional riding along as aux workgroups
@@ -1322,10 +1415,17 @@ int launch_visible(const qbm_rbm_params* P, const void* h, int h_dtype, int B, f
                : launch_visible_t<float>(P, h, B, p_v, v_s, v_s8, p_y, y1hot, seed, offset_v, offset_y, row0, st);
 }
 
-template <class T0, class T1>
+// what the gradient launch of the discriminative step carries besides the strips (kind D workgroups, one phase)
+struct DiscExtras {
+    const float* pre; const float* U; const float* pyx; const int* labels; const float* rowloss; double* loss_acc;
+    float* dgU; float* dgc; float* duU; float* duc; float* dub;
+};
+
+template <class T0, class T1, bool PAR>
 int launch_grad_t(int V, int H, int C, int B, const void* A0, const float* Y0, const float* P0, const void* A1,
                   const float* Y1, const float* P1, const qbm_rbm_grads* G, float* W_fused, const qbm_rbm_params* aux_fused,
-                  float lr, float factor, float bs, float sparse, hipStream_t st, const float* gU_sub, const uint32_t* status)
+                  float lr, float factor, float bs, float sparse, hipStream_t st, const float* gU_sub, const uint32_t* status,
+                  const DiscExtras* dx, const float* mon_rowloss, double* mon_loss_acc)
 {
     constexpr int MT = G_MT, NT = G_NT;
     const int nM = (V + 16 * MT - 1) / (16 * MT), nN = (H + 16 * NT - 1) / (16 * NT);
@@ -1336,11 +1436,22 @@ int launch_grad_t(int V, int H, int C, int B, const void* A0, const float* Y0, c
                aux_fused ? aux_fused->U : nullptr, aux_fused ? aux_fused->c : nullptr,
                lr, factor, bs, sparse, B, V, H, C, panel_for<MT, NT, 4>(B),
                nN, want_b ? nM : 0, want_c ? (C + 16 * NT - 1) / (16 * NT) : 0,
-               (H % 4 == 0) && (!G->gW || aligned16(G->gW)) && (!W_fused || aligned16(W_fused)), gU_sub, 0, status, G->n_rows};
-    const bool fast = (B % 16 == 0) && (V % 16 == 0) && (H % 4 == 0) && aligned16(A0) && aligned16(A1) && aligned16(P0) &&
+               (H % 4 == 0) && (!G->gW || aligned16(G->gW)) && (!W_fused || aligned16(W_fused)), gU_sub, 0, status, G->n_rows,
+               0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (mon_rowloss && mon_loss_acc) { a.nL = 1; a.rowloss = mon_rowloss; a.loss_acc = mon_loss_acc; }
+    if (dx) {
+        a.nD = C * ((H + 15) / 16);
+        a.pre = dx->pre; a.Up = dx->U; a.pyx = dx->pyx; a.labels = dx->labels; a.rowloss = dx->rowloss; a.loss_acc = dx->loss_acc;
+        a.dgU = dx->dgU; a.dgc = dx->dgc; a.duU = dx->duU; a.duc = dx->duc; a.dub = dx->dub;
+    }
+    const bool fast = (B % 16 == 0) && (V % 16 == 0) && (H % 4 == 0) && aligned16(A0) && (!P1 || aligned16(A1)) && aligned16(P0) &&
                       aligned16(P1) && small2g((long)B * V, 4) && small2g((long)B * H, 4);
-    const int grid = a.nU + a.nB + a.nC + nM * nN;
-    constexpr bool PAR = sizeof(T0) == 1 && sizeof(T1) == 1;
+    const int grid = a.nU + a.nB + a.nC + nM * nN + a.nD + a.nL;
+    // PAR: the phases side by side (both operands uint8, two phases); otherwise 256 threads, phase after phase -- or one
+    // phase only (P1 == null: the discriminative step)
+    static_assert(!PAR || (sizeof(T0) == 1 && sizeof(T1) == 1), "the phase-parallel kernel takes uint8 data");
+    if (PAR && (!P1 || dx)) return fail(QBM_ERR_ARG, "two_phase_grad: the one-phase form takes the 256-thread kernel");
+    if (dx && P1) return fail(QBM_ERR_ARG, "two_phase_grad: kind D workgroups ride with the one-phase form only");
     size_t lds;
     if constexpr (PAR) {
         // one staging region per phase group, sized for the largest of the four kinds of workgroup (uint8 data; the class
@@ -1355,15 +1466,29 @@ int launch_grad_t(int V, int H, int C, int B, const void* A0, const float* Y0, c
         if (lds < swap_bytes) lds = swap_bytes;
         if (lds > 163840) return fail(QBM_ERR_ARG, "two_phase_grad: LDS budget exceeded");
     } else {
-        lds = strip_lds_bytes<MT, NT, 4>(a.KP);  // the fp32 operands set the budget
+        constexpr int ASZ = sizeof(T0) == 1 && sizeof(T1) == 1 ? 1 : 4;   // an fp32 operand sets the budget
+        lds = strip_lds_bytes<MT, NT, ASZ>(a.KP);
+        if (lds < (size_t)strip_lds_bytes<1, NT, 4>(a.KP)) lds = strip_lds_bytes<1, NT, 4>(a.KP);   // kinds U, C: synthesised fp32 tile
+        if (lds < 24576) lds = 24576;                                                                // kind D / kind L: their LDS arrays
     }
-    if (fast) {
-        if (int rc = set_lds(k_grad<T0, T1, true, PAR>, lds)) return rc;
-        hipLaunchKernelGGL((k_grad<T0, T1, true, PAR>), dim3(grid), dim3(PAR ? 512 : 256), lds, st, a);
+#define QBM_LAUNCH(F, ONE)                                                                                     \
+    {                                                                                                           \
+        if (int rc = set_lds(k_grad<T0, T1, F, PAR, ONE>, lds)) return rc;                                      \
+        hipLaunchKernelGGL((k_grad<T0, T1, F, PAR, ONE>), dim3(grid), dim3(PAR ? 512 : 256), lds, st, a);       \
+    }
+    if constexpr (PAR) {
+        if (fast) QBM_LAUNCH(true, false) else QBM_LAUNCH(false, false)
+    } else if (dx) {   // one phase + kind D: instantiated for A0 = A1 types only (the discriminative step hands x over twice)
+        if constexpr (std::is_same<T0, T1>::value) {
+            if (fast) QBM_LAUNCH(true, true) else QBM_LAUNCH(false, true)
+        } else {
+            return fail(QBM_ERR_ARG, "two_phase_grad: the one-phase form takes one operand type");
+        }
     } else {
-        if (int rc = set_lds(k_grad<T0, T1, false, PAR>, lds)) return rc;
-        hipLaunchKernelGGL((k_grad<T0, T1, false, PAR>), dim3(grid), dim3(PAR ? 512 : 256), lds, st, a);
+        if (!P1) return fail(QBM_ERR_ARG, "two_phase_grad: second phase missing");
+        if (fast) QBM_LAUNCH(true, false) else QBM_LAUNCH(false, false)
     }
+#undef QBM_LAUNCH
     QBM_CHECK_LAUNCH("k_grad");
     return QBM_OK;
 }
@@ -1371,12 +1496,14 @@ int launch_grad_t(int V, int H, int C, int B, const void* A0, const float* Y0, c
 int launch_grad(int V, int H, int C, int B, const void* A0, int d0, const float* Y0, const float* P0, const void* A1, int d1,
                 const float* Y1, const float* P1, const qbm_rbm_grads* G, float* W_fused, const qbm_rbm_params* aux_fused,
                 float lr, float factor, float bs, float sparse, hipStream_t st, const float* gU_sub = nullptr,
-                const uint32_t* status = nullptr)
+                const uint32_t* status = nullptr, const DiscExtras* dx = nullptr, const float* mon_rowloss = nullptr,
+                double* mon_loss_acc = nullptr)
 {
     if (C + 1 > 16) return fail(QBM_ERR_ARG, "two_phase_grad: at most 15 classes (class rows + the bias row share one 16-row tile)");
-#define QBM_G(T0, T1) launch_grad_t<T0, T1>(V, H, C, B, A0, Y0, P0, A1, Y1, P1, G, W_fused, aux_fused, lr, factor, bs, sparse, st, gU_sub, status)
-    if (d0 == QBM_U8) return d1 == QBM_U8 ? QBM_G(uint8_t, uint8_t) : QBM_G(uint8_t, float);
-    return d1 == QBM_U8 ? QBM_G(float, uint8_t) : QBM_G(float, float);
+#define QBM_G(T0, T1, PAR) launch_grad_t<T0, T1, PAR>(V, H, C, B, A0, Y0, P0, A1, Y1, P1, G, W_fused, aux_fused, lr, factor, bs, sparse, st, gU_sub, status, dx, mon_rowloss, mon_loss_acc)
+    if (d0 == QBM_U8 && d1 == QBM_U8) return (P1 && !dx) ? QBM_G(uint8_t, uint8_t, true) : QBM_G(uint8_t, uint8_t, false);
+    if (d0 == QBM_U8) return QBM_G(uint8_t, float, false);
+    return d1 == QBM_U8 ? QBM_G(float, uint8_t, false) : QBM_G(float, float, false);
 #undef QBM_G
 }
 
@@ -1542,7 +1669,7 @@ int qbm_rbm_free_energy(const qbm_rbm_params* P, const float* x, int B, float* p
 #define QBM_L(CM)                                                                                               \
     hipLaunchKernelGGL((k_free_energy<CM>), dim3(B), dim3(64 * P->C), 0, (hipStream_t)stream, pre_ws, P->U,             \
                        P->c, neg_free_energy, p_y_given_x, B, P->H, P->C, (const int*)nullptr, (float*)nullptr,   \
-                       (float*)nullptr, (float*)nullptr)
+                       (float*)nullptr)
     QBM_DISPATCH_CM(P->C, QBM_L);
 #undef QBM_L
     QBM_CHECK_LAUNCH("k_free_energy");
@@ -1599,7 +1726,7 @@ int qbm_f32_to_u8(const float* x, uint8_t* y, long n, void* stream)
 
 static int cd_chain_impl(const qbm_rbm_params* P, const void* v0, int v0_dtype, const float* y0, int B, int k, uint64_t seed,
                          uint64_t offset, uint32_t row0, uint8_t* chain_v, float* chain_y, const qbm_rbm_cd_workspace* ws,
-                         void* stream, bool* fused)
+                         void* stream, bool* fused, float* mon_pre = nullptr)
 {
     *fused = false;
     if (int rc = check_params(P)) return rc;
@@ -1616,12 +1743,13 @@ static int cd_chain_impl(const qbm_rbm_params* P, const void* v0, int v0_dtype, 
         *fused = done;
         if (done) return QBM_OK;
     }
+    // (mon_pre: the training loop's monitor wants v0.W + d -- one more store of the positive-phase launch)
     if (chain_v) {
         // positive phase on the data (probabilities only), negative chain from the persistent state
-        if (int rc = launch_hidden(P, v0, v0_dtype, y0, B, ws->ph0, nullptr, nullptr, 0, seed, offset, row0, st)) return rc;
+        if (int rc = launch_hidden(P, v0, v0_dtype, y0, B, ws->ph0, nullptr, nullptr, 0, seed, offset, row0, st, mon_pre)) return rc;
         if (int rc = launch_hidden(P, chain_v, QBM_U8, chain_y, B, nullptr, nullptr, ws->h, 0, seed, offset, row0, st)) return rc;
     } else {
-        if (int rc = launch_hidden(P, v0, v0_dtype, y0, B, ws->ph0, nullptr, ws->h, 0, seed, offset, row0, st)) return rc;
+        if (int rc = launch_hidden(P, v0, v0_dtype, y0, B, ws->ph0, nullptr, ws->h, 0, seed, offset, row0, st, mon_pre)) return rc;
     }
     for (int t = 1; t <= k; ++t) {
         const uint64_t o = offset + 3ull * (uint64_t)t;
@@ -1655,16 +1783,34 @@ int qbm_rbm_cd_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void*
     if (!fuse_update && (!G->gW || !G->gb || !G->gd || !G->gU || !G->gc))
         return fail(QBM_ERR_ARG, "cd_step: all gradient blocks are required without fuse_update");
     bool fused = false;
-    if (int rc = cd_chain_impl(P, v0, v0_dtype, y0, B, k, seed, offset, row0, chain_v, chain_y, ws, stream, &fused)) return rc;
+    // the training loop's monitor (ws->mon_*): p(y|x0) under the parameters BEFORE this step's update (what
+    // discriminative_training reports too, src/ClassificationRBM.py:108, :142) and its two loss terms
+    const bool mon = ws && ws->mon_labels && ws->mon_pre && ws->mon_p && ws->mon_rowloss && ws->mon_loss_acc;
+    if (int rc = cd_chain_impl(P, v0, v0_dtype, y0, B, k, seed, offset, row0, chain_v, chain_y, ws, stream, &fused,
+                               mon ? ws->mon_pre : nullptr))
+        return rc;
     if (B == 0) return zero_grads(P, G, (hipStream_t)stream);
     if (!(batch_size > 0.f)) return fail(QBM_ERR_ARG, "cd_step: batch_size must be positive");
+    if (mon) {
+        hipStream_t st = (hipStream_t)stream;
+        // the one-launch chain does not deliver v0.W + d: one contraction of its own
+        if (fused)
+            if (int rc = launch_hidden(P, v0, v0_dtype, nullptr, B, ws->mon_pre, nullptr, nullptr, 1, 0, 0, 0, st)) return rc;
+#define QBM_L(CM)                                                                                                         \
+    hipLaunchKernelGGL((k_free_energy<CM>), dim3(B), dim3(64 * P->C), 0, st, ws->mon_pre, P->U, P->c, (float*)nullptr, ws->mon_p, \
+                       B, P->H, P->C, ws->mon_labels, (float*)nullptr, ws->mon_rowloss)
+        QBM_DISPATCH_CM(P->C, QBM_L);
+#undef QBM_L
+        QBM_CHECK_LAUNCH("k_free_energy");
+    }
     qbm_rbm_grads g = *G;
     if (fuse_update) g.gW = nullptr;  // the whole update happens inside the gradient launch
     // PCD: (v_k, y_k) live in the persistent chains.  Behind the one-launch chain the gradient launch reads the chain's status
     // word: a chain that gave up (or an earlier one on this workspace that did) never reaches gradients or parameters.
     return launch_grad(P->V, P->H, P->C, B, v0, v0_dtype, y0, ws->ph0, chain_v ? chain_v : ws->vk, QBM_U8,
                        chain_v ? chain_y : ws->yk, ws->phk, &g, fuse_update ? P->W : nullptr, fuse_update ? P : nullptr, lr,
-                       factor, batch_size, sparse_constant, (hipStream_t)stream, nullptr, fused ? ws->sync + 512 : nullptr);
+                       factor, batch_size, sparse_constant, (hipStream_t)stream, nullptr, fused ? ws->sync + 512 : nullptr, nullptr,
+                       mon ? ws->mon_rowloss : nullptr, mon ? ws->mon_loss_acc : nullptr);
 }
 
 int qbm_rbm_disc_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const float* x, const int32_t* labels, int B,
@@ -1684,36 +1830,39 @@ int qbm_rbm_disc_step_ex(const qbm_rbm_params* P, const qbm_rbm_grads* G, const 
     if (B < 0) return fail(QBM_ERR_ARG, "B < 0");
     if (B == 0) return zero_grads(P, G, (hipStream_t)stream);
     if (!G || !G->gd || !G->gU || !G->gc) return fail(QBM_ERR_ARG, "disc_step: gd, gU, gc are required");
-    if (!x || !labels || !p_y || !ws || !ws->pre || !ws->pos || !ws->neg || !ws->onehot || !ws->cls_neg)
+    if (!x || !labels || !p_y || !ws || !ws->pre || !ws->diff || !ws->rowloss)
         return fail(QBM_ERR_ARG, "disc_step: null buffer");
     const bool fuse = apply_update && fuse_update;
     if (!fuse && !G->gW) return fail(QBM_ERR_ARG, "disc_step: gW is required unless the update is fused");
     if (apply_update && !(batch_size > 0.f)) return fail(QBM_ERR_ARG, "disc_step: batch_size must be positive");
     hipStream_t st = (hipStream_t)stream;
-    // 1. pre = d + x.W   2. -F, p(y|x), pos / neg / onehot per row   3. class part: usub = sum_i o p, gc (+ c, b update)
-    // 4. gW, gU, gd from the two "phases" (x, onehot, pos) and (x, -, neg); every remaining update fused
+    // Three launches:
+    //   1. pre = d + x.W                                                          (MFMA strips)
+    //   2. per row: -F, p(y|x), diff = pos - neg, the row's two loss terms          (one workgroup per row)
+    //   3. gW = x^T.diff (ONE contraction over the batch), gd = colsum(diff) (strips); gU, gc, the minibatch's loss terms
+    //      (kind D workgroups, behind the strips: sigma(pre + U_c) is evaluated there once more rather than stored as a
+    //      [B,C,H] array); every update fused
     if (int rc = launch_hidden(P, x, x_dtype, nullptr, B, ws->pre, nullptr, nullptr, 1, 0, 0, 0, st)) return rc;
 #define QBM_L(CM)                                                                                               \
     hipLaunchKernelGGL((k_free_energy<CM>), dim3(B), dim3(64 * P->C), 0, st, ws->pre, P->U, P->c, neg_free_energy, p_y, \
-                       B, P->H, P->C, labels, ws->pos, ws->neg, ws->onehot)
+                       B, P->H, P->C, labels, ws->diff, ws->rowloss)
     QBM_DISPATCH_CM(P->C, QBM_L);
 #undef QBM_L
     QBM_CHECK_LAUNCH("k_free_energy");
-    const StepScale sc{lr, factor, batch_size, sparse_constant};
-    hipLaunchKernelGGL(k_disc_class_grad, dim3(P->C * ((P->H + 15) / 16)), dim3(256), 0, st, ws->pre, P->U, p_y, labels,
-                       ws->cls_neg, (float*)nullptr, G->gc, fuse ? P->c : nullptr, fuse ? P->b : nullptr, sc, B, P->H,
-                       P->C, P->V);
-    QBM_CHECK_LAUNCH("k_disc_class_grad");
     qbm_rbm_grads g = *G;
     g.gb = nullptr;  // reference: visible_bias_grad = 0 (src/ClassificationRBM.py:138)
-    g.gc = nullptr;  // written by k_disc_class_grad above
+    g.gU = nullptr;  // class-weight and class-bias gradients come from the kind D workgroups
+    g.gc = nullptr;
     if (fuse) g.gW = nullptr;
-    qbm_rbm_params aux{nullptr, nullptr, P->d, P->U, nullptr, P->V, P->H, P->C};
-    if (int rc = launch_grad(P->V, P->H, P->C, B, x, x_dtype, ws->onehot, ws->pos, x, x_dtype, nullptr, ws->neg, &g,
+    const DiscExtras dx{ws->pre, P->U, p_y, labels, ws->rowloss, ws->loss_acc, G->gU, G->gc,
+                        fuse ? P->U : nullptr, fuse ? P->c : nullptr, fuse ? P->b : nullptr};
+    qbm_rbm_params aux{nullptr, nullptr, P->d, nullptr, nullptr, P->V, P->H, P->C};
+    if (int rc = launch_grad(P->V, P->H, P->C, B, x, x_dtype, nullptr, ws->diff, nullptr, x_dtype, nullptr, nullptr, &g,
                              fuse ? P->W : nullptr, fuse ? &aux : nullptr, lr, factor, batch_size, sparse_constant, st,
-                             ws->cls_neg))
+                             nullptr, nullptr, &dx))
         return rc;
     if (apply_update && !fuse) {
+        g.gU = G->gU;
         g.gc = G->gc;
         return qbm_rbm_update(P, &g, lr, factor, batch_size, sparse_constant, stream);
     }

@@ -189,31 +189,39 @@ class HipRbmOps:
 
     # ---- training steps -----------------------------------------------------------------------
     def disc_step(self, P: ParamSet, G: GradSet, x, labels, apply_update, fuse, lr, factor, batch_size, sparse,
-                  with_count=False):
+                  with_count=False, loss_acc=None, p_out=None):
         """One discriminative_training pass (src/ClassificationRBM.py:101-140). -> p(y|x) [B,C]
         x: fp32, or uint8 {0,1} (binary inputs stay bytes: the uint8 kernels, same values).
-        with_count: the gradient launch also stores its row count in G.count (the data-parallel path all-reduces it)."""
+        with_count: the gradient launch also stores its row count in G.count (the data-parallel path all-reduces it).
+        loss_acc: float64 [2] device tensor; the step adds the minibatch's CrossEntropyLoss-on-probabilities (:142) and
+        -log(p_y + 1e-8) mean (:188-191) to it -- the training loop's bookkeeping without a launch or a sync of its own.
+        p_out: where p(y|x) goes (default: a fresh tensor; `False`: a scratch buffer nobody reads)."""
         x, xd = _state(x, self.device)
         if not (torch.is_tensor(labels) and labels.dtype == torch.int32 and labels.device == self.device
                 and labels.is_contiguous()):
             labels = torch.as_tensor(labels).to(device=self.device, dtype=torch.int32).contiguous()
         B = x.shape[0]
-        key = (B, P.H, P.C)
+        key = (B, P.H, P.C, 0 if loss_acc is None else loss_acc.data_ptr())
         if self._disc_ws is None or self._disc_ws[0] != key:   # scratch reused from step to step (stream-ordered)
             f = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.device)
-            bufs = (f(B, P.H), f(B, P.H), f(B, P.H), f(B, P.C), f(P.C, P.H))
-            self._disc_ws = (key, bufs, DiscWorkspace(*(ptr(t) for t in bufs)))
+            bufs = (f(B, P.H), f(B, P.H), f(B, 2), f(B, P.C))
+            self._disc_ws = (key, bufs, DiscWorkspace(ptr(bufs[0]), ptr(bufs[1]), ptr(bufs[2]), ptr(loss_acc)), loss_acc)
         ws = self._disc_ws[2]
-        p = torch.empty(B, P.C, dtype=torch.float32, device=self.device)
-        ps, gs = P.struct(), G.struct(with_gb=False, with_count=with_count)
-        check(self.lib.qbm_rbm_disc_step_ex(C.byref(ps), C.byref(gs), ptr(x), xd, ptr(labels), B, ptr(p), None, C.byref(ws),
-                                            int(apply_update), int(fuse), lr, factor, batch_size, sparse,
-                                            current_stream()), "qbm_rbm_disc_step_ex")
-        return p
+        if p_out is None:
+            p_out = torch.empty(B, P.C, dtype=torch.float32, device=self.device)
+        elif p_out is False:
+            p_out = self._disc_ws[1][3]
+        check(self.lib.qbm_rbm_disc_step_ex(C.byref(P.struct()), C.byref(G.struct(with_gb=False, with_count=with_count)), ptr(x), xd,
+                                            ptr(labels), B, ptr(p_out), None, C.byref(ws), int(apply_update), int(fuse), lr, factor,
+                                            batch_size, sparse, current_stream()), "qbm_rbm_disc_step_ex")
+        return p_out
 
     def cd_step(self, P: ParamSet, G: GradSet, v0, y0, k, seed, offset, row0, chain_v, chain_y, fuse, lr, factor,
-                batch_size, sparse, ws=None, with_count=False, replay=None):
+                batch_size, sparse, ws=None, with_count=False, replay=None, monitor=None):
         """CD-k / PCD step: chain + gradient (+ fused update when `fuse`).
+        monitor: (labels int32 [B] device tensor, loss_acc float64 [2] device tensor) -- the training loop's bookkeeping: the
+        step also evaluates p(y|x0) under the parameters before its update and adds the minibatch's two loss terms to
+        loss_acc (include/qbm_hip.h: qbm_rbm_cd_workspace.mon_*); the workspaces cd_step keeps only.
         v0: fp32 or uint8 {0,1} [B,V]; chain_v: uint8 [B,V] persistent state (PCD) or None.
         with_count: the gradient launch also stores its row count in G.count (the data-parallel path all-reduces it).
         replay: what to call to repeat this step should its one-launch chain give up (default: this call again; the
@@ -230,6 +238,15 @@ class HipRbmOps:
                 self.check_chain_status()
             ws = self._cd_workspace_cached(P, B)
         cws = ws[6] if len(ws) > 6 else CdWorkspace(*(ptr(t) for t in ws[:6]))
+        if own_ws:
+            if monitor is not None and B > 0:
+                if ws[7][0] is None:   # x.W + d, p(y|x), per-row loss terms: made on first use
+                    f = lambda n: torch.empty(B, n, dtype=torch.float32, device=self.device)
+                    ws[7][:] = [f(P.H), f(P.C), f(2)]
+                    cws.mon_pre, cws.mon_p, cws.mon_rowloss = (ptr(t) for t in ws[7])
+                cws.mon_labels, cws.mon_loss_acc = ptr(monitor[0]), ptr(monitor[1])
+            else:
+                cws.mon_labels = None
         check(self.lib.qbm_rbm_cd_step(C.byref(P.struct()), C.byref(G.struct(with_count=with_count)), ptr(v0), vd, ptr(y0), B, k,
                                        seed, offset, row0, ptr(chain_v), ptr(chain_y), C.byref(cws), int(fuse), lr, factor,
                                        batch_size, sparse, current_stream()), "qbm_rbm_cd_step")
@@ -238,7 +255,7 @@ class HipRbmOps:
             # next look at the status word (check_chain_status: end of an epoch, or every kPendingMax steps)
             args = (P, G, v0, y0, k, seed, offset, row0, chain_v, chain_y, fuse, lr, factor, batch_size, sparse)
             self._pending.append((int(offset) & 0xFFFFFFFF, replay if replay is not None else
-                                  (lambda: self.cd_step(*args, with_count=with_count))))
+                                  (lambda: self.cd_step(*args, with_count=with_count, monitor=monitor))))
         if chain_v is not None:   # PCD: the k-th iteration wrote straight into the chains
             return (ws[0], ws[1], chain_v, chain_y, ws[4])
         return ws[:6]
@@ -269,7 +286,7 @@ class HipRbmOps:
             if len(self._cd_wss) >= self.kWorkspaces:
                 self._cd_wss.pop(next(iter(self._cd_wss)))
             t = self.cd_workspace(P, B, fused=False)[:5] + (self._sync_buffer(),)
-            ws = self._cd_wss[key] = t + (CdWorkspace(*(ptr(x) for x in t)),)
+            ws = self._cd_wss[key] = t + (CdWorkspace(*(ptr(x) for x in t)), [None, None, None])   # + struct, monitor buffers
         self._cd_ws = (key, ws)
         return ws
 

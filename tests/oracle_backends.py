@@ -145,27 +145,33 @@ class OracleRbmOps:
         for t in (G.gW, G.gd, G.gU, G.gc) + ((G.gb,) if with_gb else ()):
             t.zero_()
 
-    def disc_step(self, P, G, x, labels, apply_update, fuse, lr, factor, batch_size, sparse, with_count=False):
+    def disc_step(self, P, G, x, labels, apply_update, fuse, lr, factor, batch_size, sparse, with_count=False, loss_acc=None,
+                  p_out=None):
         if with_count:                 # qbm_rbm_grads.n_rows: the gradient launch stores its row count
             G.count.fill_(float(len(x)))
         if len(x) == 0:
             self._zero(G, with_gb=False)
             return torch.empty(0, P.C)
         W, b, d, U, c = self._P(P)
-        gW, gd, gU, gc, p, _ = orc.rbm_disc_grad(_np(x), _np(labels, np.int32), W, d, U, c)
+        gW, gd, gU, gc, p, _, _, bl = orc.rbm_disc_grad(_np(x), _np(labels, np.int32), W, d, U, c, with_loss=True)
+        if loss_acc is not None:       # qbm_rbm_disc_workspace.loss_acc: += (double)(fp32 minibatch mean)
+            loss_acc += torch.from_numpy(bl.astype(np.float64))
         self._store(G, gW, None, gd, gU, gc)
         if apply_update:
             self.update(P, G, lr, factor, batch_size, sparse, with_gb=False)
         return torch.from_numpy(p)
 
     def cd_step(self, P, G, v0, y0, k, seed, offset, row0, chain_v, chain_y, fuse, lr, factor, batch_size, sparse,
-                ws=None, with_count=False, replay=None):
+                ws=None, with_count=False, replay=None, monitor=None):
         if with_count:
             G.count.fill_(float(len(v0)))
         if len(v0) == 0:
             self._zero(G)
             return tuple(torch.empty(0, n) for n in (P.H, P.H, P.V, P.C, P.H))
         W, b, d, U, c = self._P(P)
+        if monitor is not None:        # qbm_rbm_cd_workspace.mon_*: p(y|x0) before the update, its loss terms booked
+            _, _, p = orc.rbm_free_energy(_np(v0), W, d, U, c)
+            monitor[1].add_(torch.from_numpy(orc.rbm_class_loss(p, _np(monitor[0], np.int32))[1].astype(np.float64)))
         cv = None if chain_v is None else _np(chain_v)
         cy = None if chain_y is None else _np(chain_y)
         ph0, vk, yk, phk = orc.rbm_cd_chain(_np(v0), _np(y0), W, b, d, U, c, k, seed, offset, row0, cv, cy)
