@@ -190,20 +190,24 @@ def main():
     # ---- roofline, part 1: per-kernel launch duration with HIP events on the launching stream.  Runs BEFORE the timed
     # region: its ~3000 launches also bring the GPU to its steady clock state, so that a short timed region (the driver
     # times 20 steps = 0.6 ms) measures the same state a long one does ----------------------------------------------
-    def time_kernel(fn, reps=1000, per_graph=50):
+    def time_kernel(fn, reps=1000, per_graph=50, prologue=None):
         """average duration of one launch, back to back: `per_graph` launches captured in a hipGraph (the host's launch
         rate -- ~7 us per ctypes call -- would otherwise be what is measured), replayed reps / per_graph times between
-        two HIP events on the launching stream"""
+        two HIP events on the launching stream.  fn(stream, i): launch i of a graph; prologue(): captured once in front"""
         st = torch.cuda.current_stream()
         sp = cur()
-        for _ in range(5):
-            fn(sp)
+        if prologue:
+            prologue()
+        for i in range(5):
+            check(fn(sp, i), "per-kernel timing launch")
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             sp_g = cur()
-            for _ in range(per_graph):
-                fn(sp_g)
+            if prologue:
+                prologue()
+            for i in range(per_graph):
+                fn(sp_g, i)
         g.replay()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)
@@ -218,20 +222,38 @@ def main():
         ph0, h, vk, yk, phk = ws[:5]
         ng = _lib.RbmGrads(None, ptr(G.gb), ptr(G.gd), ptr(G.gU), ptr(G.gc))
         scratchW = P.W.clone()
-        kernels = {
-            # name: (launcher, algorithmic FLOPs per launch, launches per CD-1 step)
-            "k_hidden (sample_hidden, x2 per step)": (
-                lambda s: lib.qbm_rbm_sample_hidden_ex(C.byref(ps), ptr(v0), QBM_U8, ptr(y0), B, ptr(ph0), None, ptr(h), 42, 0, 0, s),
-                2.0 * B * V * H + 2.0 * B * NC * H, 2),
-            "k_visible (sample_visible + class conditional)": (
-                lambda s: lib.qbm_rbm_sample_visible_class_ex(C.byref(ps), ptr(h), QBM_U8, B, None, None, ptr(vk), None, ptr(yk), 42, 1, 2, 0, s),
-                2.0 * B * V * H, 1),
-            "k_grad (two-phase gradient + fused W update)": (
-                lambda s: lib.qbm_rbm_two_phase_grad(V, H, NC, B, ptr(v0), QBM_U8, ptr(y0), ptr(ph0), ptr(vk), QBM_U8, ptr(yk), ptr(phk),
-                                                     C.byref(ng), ptr(scratchW), None, lr, factor, global_B, sparse, s),
-                4.0 * B * V * H + 4.0 * B * NC * H, 1),
-        }
-        timed = {k: time_kernel(f) for k, (f, _, _) in kernels.items()}
+        # the tail of the step -- last hidden phase + gradient + update -- is ONE launch (k_hgrad) where the library takes it
+        # (qbm_rbm_cd_tail refuses otherwise: then the step is k_hidden x2, k_visible, k_grad)
+        tws = ops.cd_workspace(P, B)
+        tcws = CdWorkspace(*(ptr(t) for t in tws))
+        tP = ParamSet(scratchW, P.b.clone(), P.d.clone(), P.U.clone(), P.c.clone())
+        tps = tP.struct()
+        tws[0].copy_(ph0)
+        tail = lambda s, i: lib.qbm_rbm_cd_tail(C.byref(tps), C.byref(ng), ptr(v0), QBM_U8, ptr(y0), B, ptr(vk), ptr(yk), C.byref(tcws), 1,
+                                                lr, factor, global_B, sparse, i + 1, s)
+        fused_tail = lib.qbm_rbm_cd_tail(C.byref(tps), C.byref(ng), ptr(v0), QBM_U8, ptr(y0), B, ptr(vk), ptr(yk), C.byref(tcws), 1,
+                                         lr, factor, global_B, sparse, 1, cur()) == 0
+        torch.cuda.synchronize()
+        hid = lambda s, i: lib.qbm_rbm_sample_hidden_ex(C.byref(ps), ptr(v0), QBM_U8, ptr(y0), B, ptr(ph0), None, ptr(h), 42, 0, 0, s)
+        vis = lambda s, i: lib.qbm_rbm_sample_visible_class_ex(C.byref(ps), ptr(h), QBM_U8, B, None, None, ptr(vk), None, ptr(yk), 42, 1, 2, 0, s)
+        grd = lambda s, i: lib.qbm_rbm_two_phase_grad(V, H, NC, B, ptr(v0), QBM_U8, ptr(y0), ptr(ph0), ptr(vk), QBM_U8, ptr(yk), ptr(phk),
+                                                      C.byref(ng), ptr(scratchW), None, lr, factor, global_B, sparse, s)
+        f_hid, f_vis, f_grd = 2.0 * B * V * H + 2.0 * B * NC * H, 2.0 * B * V * H, 4.0 * B * V * H + 4.0 * B * NC * H
+        # name: (launcher, algorithmic FLOPs per launch, launches per CD-1 step, prologue of the timing graph)
+        if fused_tail:
+            kernels = {
+                "k_hidden (sample_hidden)": (hid, f_hid, 1, None),
+                "k_visible (sample_visible + class conditional)": (vis, f_vis, 1, None),
+                # rounds 1..50 of a timing graph on flag words re-zeroed at its start (include/qbm_hip.h: qbm_rbm_cd_tail)
+                "k_hgrad (last sample_hidden + two-phase gradient + update, one launch)": (tail, f_hid + f_grd, 1, lambda: tws[5][576:1600].zero_()),
+            }
+        else:
+            kernels = {
+                "k_hidden (sample_hidden, x2 per step)": (hid, f_hid, 2, None),
+                "k_visible (sample_visible + class conditional)": (vis, f_vis, 1, None),
+                "k_grad (two-phase gradient + fused W update)": (grd, f_grd, 1, None),
+            }
+        timed = {k: time_kernel(f, prologue=pro) for k, (f, _, _, pro) in kernels.items()}
 
     # warm-up: at least W steps, through the launch path that is timed (whole graph replays when steps are captured)
     warm_steps = args.warmup if graphs is None else -(-args.warmup // graphs[1]) * graphs[1]
@@ -248,6 +270,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(P.W).all(), "parameters diverged"
+    assert int(ws[5][512].item()) == 0, "a launch that synchronises workgroups inside an XCD gave up during the timed run"
 
     ms_per_step = dt / args.steps * 1e3
     value = B * K_CD * args.steps * world / dt
@@ -295,6 +318,8 @@ def main():
             "config": {"workload": "ClassificationRBM 784v x 512h, C=10, CD-1, batch 256 per GPU (BASELINE.json configs[3] shape; "
                                    "global batch 256*N, RCCL all-reduce of the flat gradient per step when N>1)",
                        "batch_per_gpu": B, "cd_k": K_CD, "warmup_steps_run": warm_steps,
+                       "pre_timed_kernel_launches": (1000 + 55 + 5) * len(timed) if rank == 0 else 0,
+                       "launches_per_step": "k_hidden, k_visible, k_hgrad" if (rank == 0 and any("k_hgrad" in k for k in timed)) else "k_hidden, k_visible, k_hidden, k_grad (+ all-reduce, k_update when data-parallel)",
                        "draws": "a replayed graph repeats the draw ids and minibatches it captured (same work per step)" if graphs else "fresh draw ids per step", "launch": (f"hipGraph x{graphs[1]} steps" if graphs else "eager") + (f" ({graph_note})" if graph_note else ""),
                        "parallelism": f"dp{world}" + (" (forced data-parallel path)" if args.force_dp and world == 1 else "")},
             "visible_unit_updates_per_sec": round(value * V, 1),

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QBM_ABI_VERSION 11
+#define QBM_ABI_VERSION 12
 #define QBM_MAX_CLASSES 15 /* class rows + the bias row share one 16-row gradient tile */
 #define QBM_MAX_QUBO_VARS 1024
 
@@ -163,16 +163,23 @@ typedef struct {
     float* yk;    /* [B,C] one-hot */
     float* phk;   /* [B,H] */
     uint32_t* sync; /* [QBM_CD_SYNC_WORDS] uint32, zeroed once by the caller and then left alone, or NULL: state of the
-                     * fused chain kernel (round flags of its XCD-local barriers, the XCC ids, status word at index 512:
-                     * 0 = fine, 1 = a barrier timed out, 2 = workgroups of a row block on different XCDs; words 513 / 514:
-                     * `offset` (low / high half) of the launch that gave up).  FAIL-SAFE: the gradient launch of
-                     * qbm_rbm_cd_step behind a chain that gave up writes nothing (parameters and gradient blocks keep their
-                     * values, n_rows becomes -inf), and every later one-launch chain and gradient on this buffer does
-                     * nothing either, until the caller has re-zeroed the buffer -- a failed chain never reaches the
-                     * parameters.  The caller then repeats the skipped steps with qbm_rbm_fused_chain_mode(0): same draws,
-                     * same bits (rbm_ops.HipRbmOps.check_chain_status does exactly that).  NULL = always the
-                     * launch-per-phase path.  One buffer per stream of concurrent work; workspaces of different
-                     * shapes on one stream may share it. */
+                     * launches that synchronise workgroups of one XCD among themselves -- the one-launch chain (k_chain) and
+                     * the fused tail of a step (k_hgrad: last hidden phase + gradient + update): round flags of their
+                     * XCD-local barriers, the XCC ids, per-workgroup completion marks, and the status word at index 512:
+                     * 0 = fine; 1 / 2 = the one-launch chain gave up (a barrier timed out / workgroups of a row block on
+                     * different XCDs); 3 / 4 = the fused tail gave up (barrier / placement).  Words 513 / 514: `offset`
+                     * (low / high half) of the step that gave up; word 515: the round of a fused tail that gave up (516: round counter).
+                     * FAIL-SAFE: while the status word is set, EVERY later launch of qbm_rbm_cd_step on this buffer stores
+                     * nothing (n_rows becomes -inf), and so does qbm_rbm_update_dev when handed the word.  Status 1 / 2:
+                     * the step's gradient launch did nothing either -- parameters and workspace are as before the step,
+                     * which the caller repeats with qbm_rbm_fused_chain_mode(0) after re-zeroing the buffer.  Status 3 / 4
+                     * with fuse_update: the column groups that got through their barrier HAVE been updated, the others
+                     * not -- the caller calls qbm_rbm_cd_step_finish with the step's arguments and word 515 BEFORE re-zeroing
+                     * (it completes exactly what is missing: same bits as an undisturbed step), then repeats the LATER
+                     * steps; without fuse_update the parameters are untouched (qbm_rbm_update_dev is handed the status
+                     * word or the -inf row count) and the step is repeated like a failed chain.
+                     * rbm_ops.HipRbmOps.check_chain_status does all of this.  NULL = always one launch per phase.  One
+                     * buffer per stream of concurrent work; workspaces of different shapes on one stream may share it. */
     /* The training loop's monitor, qbm_rbm_cd_step only (all five set, or mon_labels NULL = off): the step also evaluates
      * p(y|x0) of its minibatch under the parameters BEFORE its update -- what discriminative_training reports
      * (src/ClassificationRBM.py:108, :142) -- from v0.W + d, which the positive-phase launch stores on the way (one more
@@ -184,7 +191,7 @@ typedef struct {
     float* mon_rowloss;        /* [B,2] */
     double* mon_loss_acc;      /* [2] */
 } qbm_rbm_cd_workspace;
-#define QBM_CD_SYNC_WORDS 576
+#define QBM_CD_SYNC_WORDS 3136
 
 /* k-step block-Gibbs chain (declared, never implemented in the reference:
  * src/ClassificationRBM.py:19, :179-182).  v0[B,V] fp32 or uint8 (v0_dtype), y0[B,C] fp32.
@@ -199,8 +206,11 @@ QBM_API int qbm_rbm_cd_chain(const qbm_rbm_params* P, const void* v0, int v0_dty
                              uint64_t seed, uint64_t offset, uint32_t row0, uint8_t* chain_v, float* chain_y,
                              const qbm_rbm_cd_workspace* ws, void* stream);
 
-/* When qbm_rbm_cd_chain / qbm_rbm_cd_step use the one-launch chain kernel: 0 = never, 1 = where it is faster (from k = 2
- * on; the default, or the first character of the environment variable QBM_FUSED_CHAIN), 2 = whenever the shape allows.
+/* When qbm_rbm_cd_chain / qbm_rbm_cd_step use the launches that synchronise workgroups inside an XCD: 0 = never (one launch
+ * per phase, then the gradient), 1 = where they are faster (the default, or the first character of the environment variable
+ * QBM_FUSED_CHAIN): the one-launch chain from k = 2 on; 2 = the one-launch chain whenever the shape allows; 3 = as 1, plus
+ * the fused tail (last hidden phase + gradient + update in one launch, k_hgrad: CD-1 is then three launches) where the shape
+ * allows -- an opt-in: measured slower than the launch-per-phase tail.  All give the same bits.
  * Process-wide; returns the previous mode (an out-of-range argument only queries). */
 QBM_API int qbm_rbm_fused_chain_mode(int mode);
 
@@ -212,6 +222,25 @@ QBM_API int qbm_rbm_cd_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, con
                             const float* y0, int B, int k, uint64_t seed, uint64_t offset, uint32_t row0,
                             uint8_t* chain_v, float* chain_y, const qbm_rbm_cd_workspace* ws, int fuse_update,
                             float lr, float factor, float batch_size, float sparse_constant, void* stream);
+
+/* Completes a step whose fused tail gave up (qbm_rbm_cd_workspace.sync: status 3 / 4): the arguments of that
+ * qbm_rbm_cd_step call and word 515 of the sync buffer as `round`; to be called before the buffer is re-zeroed and before
+ * anything else touches the workspace.  Two launches: the hidden phases, then the gradient items, that the workgroups of
+ * the failed launch did not complete. */
+QBM_API int qbm_rbm_cd_step_finish(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void* v0, int v0_dtype,
+                                   const float* y0, int B, int k, uint64_t seed, uint64_t offset, uint32_t row0,
+                                   uint8_t* chain_v, float* chain_y, const qbm_rbm_cd_workspace* ws, int fuse_update,
+                                   float lr, float factor, float batch_size, float sparse_constant, uint32_t round,
+                                   void* stream);
+
+/* The fused tail of a CD step by itself (what qbm_rbm_cd_step launches last where the shape allows -- uint8 data, B a multiple
+ * of 16 up to 256, H a multiple of 128 up to 512, at most 256 strips of 32 rows x 16 hidden units, qbm_rbm_fused_chain_mode 3 --
+ * else QBM_ERR_ARG; mode 3 only): p(h_k) = sigma(vk.W + d + yk.U) -> ws->phk, then the two-phase gradient of (v0, y0, ws->ph0) against
+ * (vk, yk, ws->phk) and, with fuse_update, the update: ONE launch (k_hgrad).  `round` > 0 numbers the launch on ws->sync:
+ * larger than every round used on that buffer before (qbm_rbm_cd_step counts in word 516), or words 576 .. 1599 re-zeroed. */
+QBM_API int qbm_rbm_cd_tail(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void* v0, int v0_dtype, const float* y0,
+                            int B, const uint8_t* vk, const float* yk, const qbm_rbm_cd_workspace* ws, int fuse_update,
+                            float lr, float factor, float batch_size, float sparse_constant, uint32_t round, void* stream);
 
 /* caller-owned scratch of one discriminative step */
 typedef struct {
@@ -360,6 +389,10 @@ QBM_API int qbm_qbm_linear_fields(const double* X, const int32_t* labels, const 
 QBM_API int qbm_test_math(int which, const float* x, float* y, int n, void* stream);
 QBM_API int qbm_test_uniform(uint64_t seed, uint64_t offset, uint32_t row0, int rows, int cols, float* out,
                              void* stream);
+/* The next fused-tail launch (k_hgrad) of this process makes workgroup `workgroup` misbehave -- kind 1: it leaves at its
+ * start without a trace (as one that was not resident in time: its partners' barrier times out), kind 2: it gives up in
+ * front of the barrier (its partners go on) -- so that tests can walk the fail-safe without a real fault.  -1 = off. */
+QBM_API int qbm_test_hgrad_fault(int workgroup, int kind);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libqbm_hip.so")
 
-QBM_ABI_VERSION = 11
+QBM_ABI_VERSION = 12
 QBM_MAX_CLASSES = 15
 QBM_F32, QBM_U8 = 0, 1
 
@@ -35,7 +35,7 @@ class CdWorkspace(C.Structure):
                 ("mon_loss_acc", C.c_void_p)]
 
 
-QBM_CD_SYNC_WORDS = 576
+QBM_CD_SYNC_WORDS = 3136
 
 
 class DiscWorkspace(C.Structure):
@@ -69,6 +69,10 @@ SIGNATURES = {
     "qbm_rbm_cd_chain": [_PP, _p, _i, _p, _i, _i, _u64, _u64, _u32, _p, _p, C.POINTER(CdWorkspace), _p],
     "qbm_rbm_cd_step": [_PP, _GP, _p, _i, _p, _i, _i, _u64, _u64, _u32, _p, _p, C.POINTER(CdWorkspace), _i, _f, _f,
                         _f, _f, _p],
+    "qbm_rbm_cd_step_finish": [_PP, _GP, _p, _i, _p, _i, _i, _u64, _u64, _u32, _p, _p, C.POINTER(CdWorkspace), _i, _f, _f,
+                               _f, _f, _u32, _p],
+    "qbm_rbm_cd_tail": [_PP, _GP, _p, _i, _p, _i, _p, _p, C.POINTER(CdWorkspace), _i, _f, _f, _f, _f, _u32, _p],
+    "qbm_test_hgrad_fault": [_i, _i],
     "qbm_rbm_disc_step": [_PP, _GP, _p, _p, _i, _p, _p, C.POINTER(DiscWorkspace), _i, _i, _f, _f, _f, _f, _p],
     "qbm_rbm_disc_step_ex": [_PP, _GP, _p, _i, _p, _i, _p, _p, C.POINTER(DiscWorkspace), _i, _i, _f, _f, _f, _f, _p],
     "qbm_data_binarise": [_p, C.c_long, _f, _p, _p],

@@ -89,6 +89,9 @@ struct HiddenArgs {
     int ldsCls;    // byte offset of the per-wavefront scratch of those transfers (2 KiB each) in the dynamic LDS
     float* pre;    // [B,H] or null   MODE 0 only: v.W + d WITHOUT the class term (what MODE 1 delivers), for the training
                    // loop's p(y|x) monitor (qbm_rbm_cd_workspace.mon_*): one more store instead of one more contraction
+    const uint32_t* status;   // non-null: status word of the step's workspace (sync[512]); non-zero = an earlier fused
+                              // launch on it gave up and the host has not looked yet: this launch stores nothing (the
+                              // workspace keeps what the host needs to finish that step: k_hgrad)
 };
 
 // 8 wavefronts (512 threads): wavefront q contracts chain q of the 8 the K = V terms are cut into ([Q] with NQ = 8), two
@@ -99,9 +102,10 @@ constexpr int H_NQ = 8;
 // first operand transfers inside the hook)
 // AUX: cache policy of the loads of v and y (kSc1 inside the fused chain kernel: another workgroup of the XCD wrote them
 // during this launch; FASTK == 2 only).  The body of strip (ms, ns); the caller is a 512-thread workgroup.
-template <class TA, int FASTK, int MODE, int CM, int AUX = 0>
+// post: strip_mma's hook between the contraction and the combine (k_hgrad requests the gradient's operands there)
+template <class TA, int FASTK, int MODE, int CM, int AUX = 0, class Post = NoPre>
 __device__ __forceinline__ void hidden_body(const HiddenArgs& a, int ms, int ns, char* lds, char* ldsB = nullptr,
-                                            bool b_resident = false)
+                                            bool b_resident = false, Post&& post = NoPre{})
 {
     constexpr bool FAST = FASTK >= 1;
     static_assert(AUX == 0 || FASTK == 2, "cache policies apply to the all-DMA variant");
@@ -115,6 +119,7 @@ __device__ __forceinline__ void hidden_body(const HiddenArgs& a, int ms, int ns,
     const int row = m0 + SO::row(0), j0 = n0 + SO::cg(0);
     const int i_c = min(row, a.B - 1), j_c = min(j0, a.H - 1);
     const bool with_cls = MODE == 0 && a.y != nullptr;
+    const uint32_t st_w = a.status ? *a.status : 0u;   // a scalar load issued here, consumed in front of the stores
     // Everything of the epilogue that does not depend on the contraction -- bias and class-term operands, the class chain
     // (classes c >= C enter it as 0 * 0, which is exact), the Philox draw -- is taken out of the tail of the kernel AND out
     // of its head: the operands are requested in `pre0`, i.e. behind the first operand transfers of the contraction, and
@@ -212,8 +217,8 @@ __device__ __forceinline__ void hidden_body(const HiddenArgs& a, int ms, int ns,
         }
     };
     QBM_STAMP(11);
-    const auto o = strip_mma<MT, NT, FAST, FAST, 1, NQ, true, AUX>(A, Bv, m0, n0, a.V, lds, a.KP, pre0, pre, 0, ldsB, b_resident);
-    if (o.valid(0) && row < a.B && j0 < a.H) {
+    const auto o = strip_mma<MT, NT, FAST, FAST, 1, NQ, true, AUX>(A, Bv, m0, n0, a.V, lds, a.KP, pre0, pre, 0, ldsB, b_resident, post);
+    if (o.valid(0) && row < a.B && j0 < a.H && st_w == 0u) {
         float x = o.sum[0].x + dv, pv, hv = 0.f;
         if (MODE == 0) {
             if (a.pre) a.pre[(long)row * a.H + j0] = x;
@@ -423,6 +428,10 @@ struct VisibleArgs {
     const float* U; const float* cb; float* py; float* ys;
     int C; uint64_t offset_y;
     int n_aux;  // aux workgroups come first in the grid
+    const uint32_t* status;   // as HiddenArgs::status
+    uint32_t* hg_round;       // non-null: the fused tail of the step (k_hgrad) is the next launch: this one advances the word
+                              // that launch takes its barrier round from (one writer, a kernel boundary in front of the readers:
+                              // the same number in every workgroup whatever shapes earlier launches on the buffer had)
 };
 
 // 8 wavefronts (512 threads) per strip workgroup: wavefront q contracts chain q of the 8 the K = H terms are cut into
@@ -446,6 +455,7 @@ __device__ __forceinline__ void visible_body(const VisibleArgs& a, int ms, int n
     const int i = m0 + SO::row(0), k0 = n0 + 2 * SO::cg(0);
     const bool pair = a.vecO && k0 + 1 < a.V;
     float bv[2] = {0.f, 0.f}, uu[2] = {0.f, 0.f};
+    const uint32_t st_w = a.status ? *a.status : 0u;   // a scalar load issued here, consumed in front of the stores
     auto pre0 = [&]() {
         if (pair) {
             const float2 t = *reinterpret_cast<const float2*>(a.b + k0);
@@ -467,7 +477,7 @@ __device__ __forceinline__ void visible_body(const VisibleArgs& a, int ms, int n
     };
     QBM_STAMP(11);
     const auto o = strip_mma<MT, NT, FAST, FAST, 2, NQ, true, AUX>(A, Bv, m0, n0, a.H, lds, a.KP, pre0, pre);
-    if (o.valid(0) && i < a.B && k0 < a.V) {
+    if (o.valid(0) && i < a.B && k0 < a.V && st_w == 0u) {
         const float sv[2] = {o.sum[0].x, o.sum[0].y};
         float pv[2], vv[2];
 #pragma unroll
@@ -496,6 +506,11 @@ __global__ __launch_bounds__(64 * V_NQ) void k_visible(VisibleArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int nMs = (a.B + 16 * V_MT - 1) / (16 * V_MT), nNs = (a.V + 16 * V_NT - 1) / (16 * V_NT);
+    {   // aux workgroups behind a fused launch that gave up: nothing to do (the strips test the word in front of their stores)
+        const bool is_aux = a.n_aux == a.B ? (int)blockIdx.x < a.n_aux : (int)blockIdx.x >= nMs * nNs;
+        if (a.n_aux > 0 && is_aux && a.status && *a.status != 0u) return;
+    }
+    if (a.hg_round && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && *a.status == 0u) *a.hg_round = *a.hg_round + 1u;
     if (a.n_aux == a.B) {
         // aux workgroups dealt first: the class conditional of one row each, its classes dealt to the first 4 wavefronts --
         // the shortest path to y (a wavefront that has ended takes no part in the workgroup's barriers)
@@ -580,15 +595,19 @@ __device__ __forceinline__ uint32_t load_sc1(const uint32_t* p)
 
 // Barrier among the 32 workgroups of a group (every thread of the workgroup calls it).  false: the spin ran out.
 // Giving up: the status word (sync[512]) and, for the host's replay, the draw offset of the launch (sync[513], [514]).
-__device__ __forceinline__ void chain_give_up(uint32_t* status, uint32_t code, uint64_t offset)
+// (status[3]: the round of the launch, for the fused hidden + gradient launch whose unfinished work the host has repeated
+// -- k_hgrad)
+__device__ __forceinline__ void chain_give_up(uint32_t* status, uint32_t code, uint64_t offset, uint32_t round = 0u)
 {
     status[1] = (uint32_t)offset;
     status[2] = (uint32_t)(offset >> 32);
+    status[3] = round;
     __hip_atomic_store(status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// n: workgroups of the group (their flags are the first n words of the line); code: what a timeout records
 __device__ __forceinline__ bool group_barrier(uint32_t* flags, int j, uint32_t target, uint32_t* status, uint32_t* s_ok,
-                                              uint64_t offset)
+                                              uint64_t offset, int n = 32, uint32_t code = 1u)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's stores have reached the L2
     __syncthreads();
@@ -597,12 +616,12 @@ __device__ __forceinline__ bool group_barrier(uint32_t* flags, int j, uint32_t t
         if (lane == 0) __hip_atomic_store(&flags[j], target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         bool ok = true;
         for (int spins = 0;; ++spins) {
-            const uint32_t f = lane < 32 ? load_sc1(&flags[lane]) : target;
+            const uint32_t f = lane < n ? load_sc1(&flags[lane]) : target;
             if (__all((int)(f - target) >= 0)) break;
             if (spins > kChainSpin) { ok = false; break; }
         }
         if (lane == 0) {
-            if (!ok) chain_give_up(status, 1u, offset);
+            if (!ok) chain_give_up(status, code, offset, target);
             *s_ok = ok ? 1u : 0u;
         }
     }
@@ -683,14 +702,14 @@ __global__ __launch_bounds__(512) void k_chain(ChainArgs a)
         if (hidden) {
             if (j < nNh) {
                 const HiddenArgs ha{vin, yin, a.W, a.d, a.U, pout, nullptr, hout, a.B, a.V, a.H, a.C, a.KPh, a.seed, off, a.row0,
-                                    true, a.ldsCls, nullptr};
+                                    true, a.ldsCls, nullptr, nullptr};
                 hidden_body<uint8_t, 2, 0, CM, kSc1>(ha, g, j, lds + a.ldsT, lds, w_resident);
                 w_resident = true;
             }
         } else {
             if (j < nNv) {
                 const VisibleArgs va{a.h, a.W, a.b, nullptr, nullptr, vout, a.B, a.V, a.H, a.KPv, a.seed, off - 2, a.row0, a.vecO,
-                                     a.U, a.c, nullptr, yout, a.C, off - 1, 0};
+                                     a.U, a.c, nullptr, yout, a.C, off - 1, 0, nullptr, nullptr};
                 visible_body<uint8_t, true, 2, 2, kSc1>(va, g, j, lds + a.ldsT);
             }
             // class conditional of the block's 32 rows, one row per wavefront, on the workgroups that have no strip -- or,
@@ -725,8 +744,9 @@ __global__ __launch_bounds__(64 * CM) void k_free_energy(const float* __restrict
                                                          const float* __restrict__ cb, float* __restrict__ negF,
                                                          float* __restrict__ p_out, int B, int H, int C,
                                                          const int* __restrict__ labels, float* __restrict__ diff,
-                                                         float* __restrict__ rowloss)
+                                                         float* __restrict__ rowloss, const uint32_t* __restrict__ status)
 {
+    if (status && *status != 0u) return;   // (the CD step's monitor behind a fused launch that gave up: HiddenArgs::status)
     __shared__ float nf_s[CM + 1], p_s[CM + 1];
     __shared__ float e_s[CM * CM];
     const int lane = threadIdx.x & 63;
@@ -838,6 +858,8 @@ struct GradArgs {
     bool vecO;
     const float* gUsub;                          // non-null: class-weight gradient = (phase0 - phase1) - gUsub
     int lds_group;                               // bytes of one group's LDS staging region
+    int lds_group0;                              // k_hgrad: byte offset of the staging area of phase 0 (behind what the hidden phase uses)
+    int lds_sok;                                 // k_hgrad: byte offset of the barrier's result word
     const uint32_t* status;                      // non-null: status word of the fused chain launch in front (sync[512]);
                                                  // non-zero = that launch gave up: this launch writes nothing (but n_rows)
     float* n_rows;                               // non-null: receives (float)B -- the data-parallel path all-reduces it with the
@@ -1002,6 +1024,124 @@ __device__ __forceinline__ void disc_class_block(const GradArgs& a, int blk, cha
         for (int m = blk * 256 + tid; m < a.V; m += a.nD * 256) a.dub[m] = upd(a.dub[m], 0.f, a, true);
 }
 
+// Epilogues of the small gradient blocks (o0 / o1: the two phases' strips as the finishing thread holds them).
+// kind U: rows 0..C-1 = class-weight rows, row C = hidden bias; 16*NT hidden columns from n0 on
+template <class SOT>
+__device__ __forceinline__ void grad_epi_u(const GradArgs& a, int n0, const SOT& o0, const SOT& o1)
+{
+#pragma unroll
+    for (int op = 0; op < SOT::NP; ++op) {
+        if (!o0.valid(op) || o0.row(op) > a.C) continue;
+        const int row = o0.row(op);
+        const float g[4] = {o0.sum[op].x - o1.sum[op].x, o0.sum[op].y - o1.sum[op].y, o0.sum[op].z - o1.sum[op].z,
+                            o0.sum[op].w - o1.sum[op].w};
+        for (int e = 0; e < 4; ++e) {
+            const int n = n0 + 4 * o0.cg(op) + e;
+            if (n >= a.H) break;
+            if (row < a.C) {
+                const long off = (long)row * a.H + n;
+                const float gu = a.gUsub ? g[e] - a.gUsub[off] : g[e];
+                if (a.gU) a.gU[off] = gu;
+                if (a.uU) a.uU[off] = upd(a.uU[off], gu, a, false);
+            } else {
+                if (a.gd) a.gd[n] = g[e];
+                if (a.ud) a.ud[n] = upd(a.ud[n], g[e], a, true);
+            }
+        }
+    }
+}
+// kind B: visible bias, rows m0 .. of the data's column sums (output column 0)
+template <class SOT>
+__device__ __forceinline__ void grad_epi_b(const GradArgs& a, int m0, const SOT& o0, const SOT& o1)
+{
+#pragma unroll
+    for (int op = 0; op < SOT::NP; ++op) {
+        if (!o0.valid(op) || o0.cg(op) != 0) continue;
+        const int m = m0 + o0.row(op);
+        if (m >= a.V) continue;
+        const float g = o0.sum[op].x - o1.sum[op].x;
+        if (a.gb) a.gb[m] = g;
+        if (a.ub) a.ub[m] = upd(a.ub[m], g, a, true);
+    }
+}
+// kind C: class bias, classes n0 .. (output row 0)
+template <class SOT>
+__device__ __forceinline__ void grad_epi_c(const GradArgs& a, int n0, const SOT& o0, const SOT& o1)
+{
+#pragma unroll
+    for (int op = 0; op < SOT::NP; ++op) {
+        if (!o0.valid(op) || o0.row(op) != 0) continue;
+        const float g[4] = {o0.sum[op].x - o1.sum[op].x, o0.sum[op].y - o1.sum[op].y, o0.sum[op].z - o1.sum[op].z,
+                            o0.sum[op].w - o1.sum[op].w};
+        for (int e = 0; e < 4; ++e) {
+            const int n = n0 + 4 * o0.cg(op) + e;
+            if (n >= a.C) break;
+            if (a.gc) a.gc[n] = g[e];
+            if (a.uc) a.uc[n] = upd(a.uc[n], g[e], a, true);
+        }
+    }
+}
+
+// One output of a W strip (thread's output `op` of StripOut SO at strip origin (m0, n0)): the gradient, and the fused update
+// on the W tile `w_old` requested before the contraction.
+template <class SO>
+__device__ __forceinline__ void grad_finish_w(const GradArgs& a, int m0, int n0, int op, const float4& s0, const float4& s1,
+                                              const float4& w_old)
+{
+    const int m = m0 + SO::row(op), nb = n0 + 4 * SO::cg(op);
+    if (!SO::valid(op) || m >= a.V || nb >= a.H) return;
+    const float g[4] = {s0.x - s1.x, s0.y - s1.y, s0.z - s1.z, s0.w - s1.w};
+    const long off = (long)m * a.H + nb;
+    if (a.vecO && nb + 3 < a.H) {
+        if (a.gW) *reinterpret_cast<float4*>(a.gW + off) = make_float4(g[0], g[1], g[2], g[3]);
+        if (a.W) {
+            float4 w = w_old;
+            w.x = upd(w.x, g[0], a, false); w.y = upd(w.y, g[1], a, false);
+            w.z = upd(w.z, g[2], a, false); w.w = upd(w.w, g[3], a, false);
+            *reinterpret_cast<float4*>(a.W + off) = w;
+        }
+        return;
+    }
+    for (int e = 0; e < 4 && nb + e < a.H; ++e) {
+        if (a.gW) a.gW[off + e] = g[e];
+        if (a.W) a.W[off + e] = upd(a.W[off + e], g[e], a, false);
+    }
+}
+
+// fused update: the W tile of output `op` (requested behind the first operand transfers)
+template <class SO>
+__device__ __forceinline__ float4 grad_w_tile(const GradArgs& a, int m0, int n0, int op)
+{
+    const int m = min(m0 + SO::row(op), a.V - 1), nb = n0 + 4 * SO::cg(op);
+    return (a.W && a.vecO && nb + 3 < a.H) ? *reinterpret_cast<const float4*>(a.W + (long)m * a.H + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// The (16 MT) x (16 NT) strip of gW at (m0, n0), both phases side by side (uint8 data, 512 threads: see below).
+template <int MT, int NT, bool FAST>
+__device__ __forceinline__ void grad_w_strip_par(const GradArgs& a, int m0, int n0, char* lds_all, int grp)
+{
+    using SO = StripOut<MT, NT>;
+    static_assert(SO::NP == 2, "the two groups share the epilogue, output 0 of every thread to group 0, output 1 to group 1");
+    char* lds = lds_all + (size_t)grp * a.lds_group;
+    const ViewCContig P0{a.P0, a.H, a.H, a.B}, P1{a.P1, a.H, a.H, a.B};
+    const ViewCContigU8 D0{reinterpret_cast<const uint8_t*>(a.A0), a.V, a.V, a.B}, D1{reinterpret_cast<const uint8_t*>(a.A1), a.V, a.V, a.B};
+    // group 0 finishes output 0 and needs phase 1's output 0; group 1 finishes output 1 and needs phase 0's output 1
+    const bool first = grp == 0;
+    float4 w_old = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto pre0 = [&]() { w_old = first ? grad_w_tile<SO>(a, m0, n0, 0) : grad_w_tile<SO>(a, m0, n0, 1); };
+    QBM_STAMP(11);
+    SO mine;
+    if (first) mine = strip_mma<MT, NT, FAST, FAST>(D0, P0, m0, n0, a.B, lds, a.KP, pre0);
+    else mine = strip_mma<MT, NT, FAST, FAST>(D1, P1, m0, n0, a.B, lds, a.KP, pre0, NoPre{}, 5);
+    const float4 keep = first ? mine.sum[0] : mine.sum[1], give = first ? mine.sum[1] : mine.sum[0];
+    float4* x = reinterpret_cast<float4*>(lds_all);   // every thread has left strip_mma: the staging regions are free
+    x[grp * 256 + ((int)threadIdx.x & 255)] = give;
+    __syncthreads();
+    const float4 got = x[(1 - grp) * 256 + ((int)threadIdx.x & 255)];
+    if (first) grad_finish_w<SO>(a, m0, n0, 0, keep, got, w_old);
+    else grad_finish_w<SO>(a, m0, n0, 1, got, keep, w_old);
+}
+
 // PAR (both data operands uint8: the Gibbs states of the CD-k / PCD step): 512 threads, the phases side by side.
 // Otherwise (fp32 data: twice the staging bytes, two regions do not fit the LDS): 256 threads, phase after phase.
 // ONE (the discriminative step): phase 0 only -- gW = A0^T.P0 -- and the kind D workgroups behind the strips; 256 threads.
@@ -1047,26 +1187,7 @@ __global__ __launch_bounds__(PAR ? 512 : 256) void k_grad(GradArgs a)
         using SOT = StripOut<1, NT>;
         QBM_TWO_PHASES(SOT, (strip_mma<1, NT, false, FAST>(Y0, P0, 0, n0, a.B, lds, a.KP)),
                        (strip_mma<1, NT, false, FAST>(Y1, P1, 0, n0, a.B, lds, a.KP)))
-#pragma unroll
-        for (int op = 0; op < o0.NP; ++op) {
-            if (!o0.valid(op) || o0.row(op) > a.C) continue;
-            const int row = o0.row(op);
-            const float g[4] = {o0.sum[op].x - o1.sum[op].x, o0.sum[op].y - o1.sum[op].y, o0.sum[op].z - o1.sum[op].z,
-                                o0.sum[op].w - o1.sum[op].w};
-            for (int e = 0; e < 4; ++e) {
-                const int n = n0 + 4 * o0.cg(op) + e;
-                if (n >= a.H) break;
-                if (row < a.C) {
-                    const long off = (long)row * a.H + n;
-                    const float gu = a.gUsub ? g[e] - a.gUsub[off] : g[e];
-                    if (a.gU) a.gU[off] = gu;
-                    if (a.uU) a.uU[off] = upd(a.uU[off], gu, a, false);
-                } else {
-                    if (a.gd) a.gd[n] = g[e];
-                    if (a.ud) a.ud[n] = upd(a.ud[n], g[e], a, true);
-                }
-            }
-        }
+        grad_epi_u(a, n0, o0, o1);
         return;
     }
     blk -= a.nU;
@@ -1076,15 +1197,7 @@ __global__ __launch_bounds__(PAR ? 512 : 256) void k_grad(GradArgs a)
         using SOT = StripOut<MT, 1>;
         QBM_TWO_PHASES(SOT, (strip_mma<MT, 1, FAST, false>(D0, ones, m0, 0, a.B, lds, a.KP)),
                        (strip_mma<MT, 1, FAST, false>(D1, ones, m0, 0, a.B, lds, a.KP)))
-#pragma unroll
-        for (int op = 0; op < o0.NP; ++op) {
-            if (!o0.valid(op) || o0.cg(op) != 0) continue;
-            const int m = m0 + o0.row(op);
-            if (m >= a.V) continue;
-            const float g = o0.sum[op].x - o1.sum[op].x;
-            if (a.gb) a.gb[m] = g;
-            if (a.ub) a.ub[m] = upd(a.ub[m], g, a, true);
-        }
+        grad_epi_b(a, m0, o0, o1);
         return;
     }
     blk -= a.nB;
@@ -1095,18 +1208,7 @@ __global__ __launch_bounds__(PAR ? 512 : 256) void k_grad(GradArgs a)
         using SOT = StripOut<1, NT>;
         QBM_TWO_PHASES(SOT, (strip_mma<1, NT, false, false>(ones, Y0, 0, n0, a.B, lds, a.KP)),
                        (strip_mma<1, NT, false, false>(ones, Y1, 0, n0, a.B, lds, a.KP)))
-#pragma unroll
-        for (int op = 0; op < o0.NP; ++op) {
-            if (!o0.valid(op) || o0.row(op) != 0) continue;
-            const float g[4] = {o0.sum[op].x - o1.sum[op].x, o0.sum[op].y - o1.sum[op].y, o0.sum[op].z - o1.sum[op].z,
-                                o0.sum[op].w - o1.sum[op].w};
-            for (int e = 0; e < 4; ++e) {
-                const int n = n0 + 4 * o0.cg(op) + e;
-                if (n >= a.C) break;
-                if (a.gc) a.gc[n] = g[e];
-                if (a.uc) a.uc[n] = upd(a.uc[n], g[e], a, true);
-            }
-        }
+        grad_epi_c(a, n0, o0, o1);
         return;
     }
     blk -= a.nC;   // index among the strips (and what stands behind them)
@@ -1127,53 +1229,13 @@ __global__ __launch_bounds__(PAR ? 512 : 256) void k_grad(GradArgs a)
     strip_coords(nM, nN, ms, ns, a.nU + a.nB + a.nC);
     const int m0 = ms * 16 * MT, n0 = ns * 16 * NT;
     using SO = StripOut<MT, NT>;
-    static_assert(SO::NP == 2, "PAR: the two groups share the epilogue, output 0 of every thread to group 0, output 1 to group 1");
-    // one output of the strip: gradient, and the fused update on the W tile `w` requested before the contraction
-    auto finish = [&](int op, const float4& s0, const float4& s1, const float4& w_old) {
-        const int m = m0 + SO::row(op), nb = n0 + 4 * SO::cg(op);
-        if (!SO::valid(op) || m >= a.V || nb >= a.H) return;
-        const float g[4] = {s0.x - s1.x, s0.y - s1.y, s0.z - s1.z, s0.w - s1.w};
-        const long off = (long)m * a.H + nb;
-        if (a.vecO && nb + 3 < a.H) {
-            if (a.gW) *reinterpret_cast<float4*>(a.gW + off) = make_float4(g[0], g[1], g[2], g[3]);
-            if (a.W) {
-                float4 w = w_old;
-                w.x = upd(w.x, g[0], a, false); w.y = upd(w.y, g[1], a, false);
-                w.z = upd(w.z, g[2], a, false); w.w = upd(w.w, g[3], a, false);
-                *reinterpret_cast<float4*>(a.W + off) = w;
-            }
-            return;
-        }
-        for (int e = 0; e < 4 && nb + e < a.H; ++e) {
-            if (a.gW) a.gW[off + e] = g[e];
-            if (a.W) a.W[off + e] = upd(a.W[off + e], g[e], a, false);
-        }
-    };
-    auto w_tile = [&](int op) {   // fused update: the W tile of output `op` (requested behind the first operand transfers)
-        const int m = min(m0 + SO::row(op), a.V - 1), nb = n0 + 4 * SO::cg(op);
-        return (a.W && a.vecO && nb + 3 < a.H) ? *reinterpret_cast<const float4*>(a.W + (long)m * a.H + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
     if constexpr (PAR) {
-        // group 0 finishes output 0 and needs phase 1's output 0; group 1 finishes output 1 and needs phase 0's output 1
-        const bool first = grp == 0;
-        float4 w_old = make_float4(0.f, 0.f, 0.f, 0.f);
-        auto pre0 = [&]() { w_old = first ? w_tile(0) : w_tile(1); };
-        QBM_STAMP(11);
-        SO mine;
-        if (first) mine = strip_mma<MT, NT, FAST, FAST>(D0, P0, m0, n0, a.B, lds, a.KP, pre0);
-        else mine = strip_mma<MT, NT, FAST, FAST>(D1, P1, m0, n0, a.B, lds, a.KP, pre0, NoPre{}, 5);
-        const float4 keep = first ? mine.sum[0] : mine.sum[1], give = first ? mine.sum[1] : mine.sum[0];
-        float4* x = reinterpret_cast<float4*>(lds_all);   // every thread has left strip_mma: the staging regions are free
-        x[grp * 256 + ((int)threadIdx.x & 255)] = give;
-        __syncthreads();
-        const float4 got = x[(1 - grp) * 256 + ((int)threadIdx.x & 255)];
-        if (first) finish(0, keep, got, w_old);
-        else finish(1, got, keep, w_old);
+        grad_w_strip_par<MT, NT, FAST>(a, m0, n0, lds_all, grp);
     } else {
         float4 w_old[SO::NP];
         auto pre0 = [&]() {
 #pragma unroll
-            for (int op = 0; op < SO::NP; ++op) w_old[op] = w_tile(op);
+            for (int op = 0; op < SO::NP; ++op) w_old[op] = grad_w_tile<SO>(a, m0, n0, op);
         };
         QBM_STAMP(11);
         const SO o0 = strip_mma<MT, NT, FAST, FAST>(D0, P0, m0, n0, a.B, lds, a.KP, pre0);
@@ -1183,9 +1245,265 @@ __global__ __launch_bounds__(PAR ? 512 : 256) void k_grad(GradArgs a)
 #pragma unroll
             for (int op = 0; op < SO::NP; ++op) o1.sum[op] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int op = 0; op < SO::NP; ++op) finish(op, o0.sum[op], o1.sum[op], w_old[op]);
+        for (int op = 0; op < SO::NP; ++op) grad_finish_w<SO>(a, m0, n0, op, o0.sum[op], o1.sum[op], w_old[op]);
     }
     QBM_STAMP(12);
+}
+
+// ---------------------------------------------------------------------------------------------
+// A-7 fused tail: the LAST hidden phase of a CD-k / PCD-k step, its two-phase gradient and the parameter update in ONE
+// launch (the launch-per-phase step of CD-1 is then three launches: k_hidden, k_visible, k_hgrad).  OPT-IN
+// (qbm_rbm_fused_chain_mode(3)): bit-identical, but measured SLOWER than k_hidden + k_grad on every shape tried (784 x 512,
+// B = 256: 34.5 us per CD-1 step against 30.2; DESIGN.md section 10 has the in-kernel stamps that say why).
+//
+// sample_hidden's grid is (row strip ms of 32 rows) x (column strip ns of 16 hidden units), and strip_coords deals the
+// workgroups of one ns to ONE XCD.  The gradient of those 16 hidden columns -- gW[:, 16 ns ..], gU[:, 16 ns ..],
+// gd[16 ns ..] -- contracts over ALL rows of the minibatch, i.e. over exactly what the nM workgroups of group ns have just
+// produced (p(h_k)[:, 16 ns ..]) and what earlier launches wrote (v_0, p(h_0), v_k, y_k).  So the group goes on behind an
+// XCD-local barrier (group_barrier: plain stores + sc1 polling, 0.3 us; the p(h_k) panel is then read with sc1 transfers
+// from the L2 its producers wrote through) instead of behind a launch boundary (1.5-1.9 us, a cold scalar cache, cold
+// operand caches), and all 256 CUs share the gradient (k_grad's 64 x 32 strips fill 208).  Work items of a group: the W
+// strips of 128 visible rows x 16 columns (MT = 8, NT = 1; both phases side by side as in k_grad: grad_w_strip_par) and
+// the [class rows | hidden bias] tile, dealt round-robin to its nM workgroups; the visible-bias strips (32 rows each), the
+// class bias and the training loop's loss terms are dealt over the groups.  Same chains as k_grad ([Q], NQ = 4 over the
+// rows): the same bits.
+//
+// FAIL-SAFE.  The barrier's spin is bounded and the XCD placement is checked (as in k_chain); a workgroup that gives up
+// records status 3 (barrier) / 4 (placement), the step's draw offset and the launch's round in sync[512..515] and leaves.
+// Other groups may already have applied their part of the update, so a step is never REPEATED from here: per workgroup
+// the launch records what it completed -- hdone[blk] = round behind its hidden phase, gdone[blk] = round behind its
+// gradient items -- every later launch on the workspace (k_hidden, k_visible, the monitor, k_hgrad, k_chain, k_grad,
+// k_update) stores nothing while the status word is set, and the host FINISHES the step (qbm_rbm_cd_step_finish: mode 1 =
+// the hidden phases not done, then mode 2 = the gradient items not done, each a launch of its own, no barrier needed) before
+// it repeats the later ones on the launch-per-phase path (rbm_ops.HipRbmOps.check_chain_status).  Columns of a group that did
+// not get through its barrier have not been touched, so the repeated hidden phases and items see the parameters the
+// original launch saw: the finished step has the bits of an undisturbed one.
+// ---------------------------------------------------------------------------------------------
+constexpr int kHgRound = 516;              // round of the next / current fused tail (sync[512..515]: status, offset, failed round)
+constexpr int kHgFlags = 576;              // [32 groups][32] round flags (one 128-byte line per group)
+constexpr int kHgIds = kHgFlags + 1024;    // [32][32] XCC ids
+constexpr int kHgHdone = kHgIds + 1024;    // [256] per workgroup: round of its last completed hidden phase
+constexpr int kHgGdone = kHgHdone + 256;   // [256] per workgroup: round of its last completed gradient items
+static_assert(kHgGdone + 256 == QBM_CD_SYNC_WORDS, "layout of qbm_rbm_cd_workspace.sync");
+constexpr int HG_MT = 4, HG_BMT = 2;       // a W item: two strips of 64 rows (one per thread group); visible-bias strips of 32 rows
+constexpr int HG_ROWS = 2 * 16 * HG_MT;    // visible rows of a W item
+
+struct HGradArgs {
+    HiddenArgs h;        // the hidden phase: v = v_k (or the persistent chains), y = y_k, p = p(h_k); no sample
+    GradArgs g;          // A0 = v_0, Y0, P0 = p(h_0), A1 = h.v, Y1 = h.y, P1 = h.p; nB / nC != 0: gb / gc wanted; nL: loss terms
+    uint32_t* sync;      // qbm_rbm_cd_workspace.sync
+    uint64_t offset;     // draw offset of the step (recorded when the launch gives up)
+    int mode;            // 0 = the step; 1 / 2 = finishing a step that gave up: its hidden phases / gradient items not done
+    uint32_t round;      // modes 1, 2: the round of the launch that gave up; mode 0: non-zero = the round to use (qbm_rbm_cd_tail)
+    int fault_wg, fault_kind;   // test hook (qbm_test_hgrad_fault): workgroup fault_wg leaves without a trace at its start (1)
+                                // or gives up in front of the barrier (2)
+};
+
+// kinds U / B / C of the gradient, both phases side by side (the 512-thread organisation of grad_w_strip_par)
+template <int NT, int AUX1>
+__device__ __forceinline__ void grad_u_item_par(const GradArgs& a, int n0, char* lds_all, int grp)
+{
+    char* lds = lds_all + (size_t)grp * a.lds_group;
+    const ViewCContig P0{a.P0, a.H, a.H, a.B}, P1{a.P1, a.H, a.H, a.B};
+    const ViewAugY Y0{a.Y0, a.C}, Y1{a.Y1, a.C};
+    using SOT = StripOut<1, NT>;
+    SOT mine, o0, o1;
+    if (grp == 0) mine = strip_mma<1, NT, false, true>(Y0, P0, 0, n0, a.B, lds, a.KP);
+    else mine = strip_mma<1, NT, false, true, 4, 4, false, 0, AUX1>(Y1, P1, 0, n0, a.B, lds, a.KP);
+    swap_strips(mine, grp, lds_all, o0, o1);
+    if (grp == 0) grad_epi_u(a, n0, o0, o1);
+}
+template <int MT>
+__device__ __forceinline__ void grad_b_item_par(const GradArgs& a, int m0, char* lds_all, int grp)
+{
+    char* lds = lds_all + (size_t)grp * a.lds_group;
+    const ViewCContigU8 D0{reinterpret_cast<const uint8_t*>(a.A0), a.V, a.V, a.B}, D1{reinterpret_cast<const uint8_t*>(a.A1), a.V, a.V, a.B};
+    const ViewOnesCol ones;
+    using SOT = StripOut<MT, 1>;
+    SOT mine, o0, o1;
+    if (grp == 0) mine = strip_mma<MT, 1, true, false>(D0, ones, m0, 0, a.B, lds, a.KP);
+    else mine = strip_mma<MT, 1, true, false>(D1, ones, m0, 0, a.B, lds, a.KP);
+    swap_strips(mine, grp, lds_all, o0, o1);
+    if (grp == 0) grad_epi_b(a, m0, o0, o1);
+}
+__device__ __forceinline__ void grad_c_item_par(const GradArgs& a, char* lds_all, int grp)
+{
+    char* lds = lds_all + (size_t)grp * a.lds_group;
+    const ViewOnesRow ones;
+    const ViewCContig Y0{a.Y0, a.C, a.C, a.B}, Y1{a.Y1, a.C, a.C, a.B};
+    using SOT = StripOut<1, 1>;
+    SOT mine, o0, o1;
+    if (grp == 0) mine = strip_mma<1, 1, false, false>(ones, Y0, 0, 0, a.B, lds, a.KP);
+    else mine = strip_mma<1, 1, false, false>(ones, Y1, 0, 0, a.B, lds, a.KP);
+    swap_strips(mine, grp, lds_all, o0, o1);
+    if (grp == 0) grad_epi_c(a, 0, o0, o1);
+}
+
+// The W item of k_hgrad: visible rows [m0w, m0w + 128) x the group's 16 hidden columns.  Thread group g (wavefronts 4g ..
+// 4g+3 = the K chains) takes rows m0w + 64 g .. and contracts BOTH phases one after the other -- o0, o1 of an output end up in
+// the same thread: no exchange, and what a wavefront keeps live is a 64 x 16 strip (a 128 x 16 strip per wavefront with the
+// phases side by side needs more registers than there are).  The two thread groups contract against the same P panel: it is
+// staged once, by group 0, into a region both read (strip_mma: ldsB / b_resident).
+// PH (strip_mma's two-call form): kIssueAB = the requests of phase 0 (+ the W tile); kIssueA = the data operand of phase 1;
+// kConsume = group 0 requests p(h_k), then both contractions and the epilogue; kWhole = everything here.
+// LDS (bytes from `lds`): phase 1 at 0: [A group 0 | A group 1 | B]; phase 0 at a.lds_group0, same layout.
+template <int PH>
+__device__ __forceinline__ void hg_w_item(const GradArgs& a, int m0w, int n0, char* lds, int grp, float4& w_old)
+{
+    constexpr int MT = HG_MT, NT = H_NT;
+    using SO = StripOut<MT, NT>;
+    static_assert(SO::NP == 1, "one output per thread");
+    const int m0 = m0w + grp * 16 * MT;
+    const ViewCContig P0{a.P0, a.H, a.H, a.B}, P1{a.P1, a.H, a.H, a.B};
+    const ViewCContigU8 D0{reinterpret_cast<const uint8_t*>(a.A0), a.V, a.V, a.B}, D1{reinterpret_cast<const uint8_t*>(a.A1), a.V, a.V, a.B};
+    const int wa = 4 * strip_wave_bytes_a<MT, NT, 1>(a.KP);          // the A tiles (later the partial strips) of one thread group
+    char* a1 = lds + grp * wa;
+    char* b1 = lds + 2 * wa;
+    char* a0 = a1 + a.lds_group0;
+    char* b0 = b1 + a.lds_group0;
+    const bool stage_b = grp == 0;
+    auto pre0 = [&]() { w_old = grad_w_tile<SO>(a, m0, n0, 0); };
+    if constexpr (PH == kIssueAB) {
+        strip_mma<MT, NT, true, true, 4, 4, false, 0, 0, kIssueAB>(D0, P0, m0, n0, a.B, a0, a.KP, pre0, NoPre{}, 8, b0, !stage_b);
+        return;
+    } else if constexpr (PH == kIssueA) {
+        strip_mma<MT, NT, true, true, 4, 4, false, 0, kSc1, kIssueA>(D1, P1, m0, n0, a.B, a1, a.KP, NoPre{}, NoPre{}, 8, b1, true);
+        return;
+    }
+    SO o0, o1;
+    if constexpr (PH == kConsume) {
+        int younger = 0;
+        if (stage_b) {
+            strip_mma<MT, NT, true, true, 4, 4, false, 0, kSc1, kIssueB>(D1, P1, m0, n0, a.B, a1, a.KP, NoPre{}, NoPre{}, 8, b1, false);
+            younger = chain_transfers_b<NT>(a.B, a.KP);
+        }
+        o0 = strip_mma<MT, NT, true, true, 4, 4, false, 0, 0, kConsume>(D0, P0, m0, n0, a.B, a0, a.KP, NoPre{}, NoPre{}, 8, b0, true, NoPre{}, younger);
+        // (the combine's barriers have drained group 0's requests of p(h_k) and ordered them for group 1)
+        o1 = strip_mma<MT, NT, true, true, 4, 4, false, 0, kSc1, kConsume>(D1, P1, m0, n0, a.B, a1, a.KP, NoPre{}, NoPre{}, 0, b1, true);
+    } else {
+        char* r = lds + (size_t)grp * strip_lds_bytes<MT, NT, 1>(a.KP);   // everything in one go: a region per thread group
+        o0 = strip_mma<MT, NT, true, true>(D0, P0, m0, n0, a.B, r, a.KP, pre0, NoPre{}, 8);
+        o1 = strip_mma<MT, NT, true, true, 4, 4, false, 0, kSc1>(D1, P1, m0, n0, a.B, r, a.KP, NoPre{}, NoPre{}, 8);
+    }
+    grad_finish_w<SO>(a, m0, n0, 0, o0.sum[0], o1.sum[0], w_old);
+}
+
+// Barrier among the workgroups of a column group + the placement check: 0 = through, else the status code to record
+__device__ __forceinline__ uint32_t hgrad_barrier(uint32_t* flags, const uint32_t* ids, int ms, int nM, uint32_t round, uint32_t my_xcc,
+                                                  uint32_t* s_ok)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's stores have reached the L2 (and its transfers the LDS)
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        if (lane == 0) __hip_atomic_store(&flags[ms], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint32_t code = 0u;
+        for (int spins = 0;; ++spins) {
+            const uint32_t f = lane < nM ? load_sc1(&flags[lane]) : round;
+            if (__all((int)(f - round) >= 0)) break;
+            if (spins > kChainSpin) { code = 3u; break; }
+        }
+        if (code == 0u) {   // all workgroups of the group on one XCD?  (their stores reached MY L2 only then)
+            const uint32_t id = lane < nM ? load_sc1(&ids[lane]) : my_xcc;
+            if (!__all((int)(id == my_xcc))) code = 4u;
+        }
+        if (lane == 0) *s_ok = code;
+    }
+    __syncthreads();
+    return *s_ok;
+}
+
+template <int CM>
+__global__ __launch_bounds__(512) void k_hgrad(HGradArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int nM = (a.h.B + 16 * H_MT - 1) / (16 * H_MT), nN = (a.h.H + 16 * H_NT - 1) / (16 * H_NT);
+    int ms, ns;
+    strip_coords(nM, nN, ms, ns);
+    uint32_t* flags = a.sync + kHgFlags + ns * 32;
+    uint32_t* ids = a.sync + kHgIds + ns * 32;
+    uint32_t* status = a.sync + 512;
+    uint32_t* hdone = a.sync + kHgHdone + blockIdx.x;
+    uint32_t* gdone = a.sync + kHgGdone + blockIdx.x;
+    const bool faulty = a.fault_wg == (int)blockIdx.x;
+    const GradArgs& ga = a.g;
+    const int grp = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);   // 0: phase-0 operands, 1: phase-1 operands
+    const int n0 = ns * 16 * H_NT;
+    const int nS = (ga.V + HG_ROWS - 1) / HG_ROWS;
+    // The workgroup's first item, if it is a W item, goes in several calls around the barrier: the operands of phase 0
+    // (written by earlier launches) are requested between the hidden phase's contraction and its combine, into the LDS the
+    // hidden phase leaves alone; the data operand of phase 1 behind the hidden phase's epilogue (into its dead staging
+    // area); both have landed when the barrier's vmcnt(0) is through.  Only p(h_k) -- 4 transfers per wavefront of thread
+    // group 0 -- is requested behind the barrier, and lands under the MFMAs of phase 0.
+    const bool split = a.mode == 0 && ms < nS;
+    uint32_t* s_ok = reinterpret_cast<uint32_t*>(lds + ga.lds_sok);   // (free whenever the barrier runs)
+    float4 w_old = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t round = a.round;
+    if (a.mode == 0) {
+        const uint32_t st = load_sc1(status);
+        if (blockIdx.x == 0 && threadIdx.x == 0 && a.g.n_rows) *a.g.n_rows = st ? -__builtin_inff() : (float)a.g.B;
+        if (st != 0u) return;              // an earlier fused launch on this workspace gave up: nothing until the host has looked
+        if (faulty && a.fault_kind == 1) return;
+        // advanced by the launch in front (VisibleArgs::hg_round), or the caller's (qbm_rbm_cd_tail): the same in every workgroup
+        round = a.round ? a.round : a.sync[kHgRound];
+        const uint32_t my_xcc = xcc_id();
+        if (threadIdx.x == 0) ids[ms] = my_xcc;
+        QBM_STAMP(5);
+        auto post = [&]() {
+            if (split) hg_w_item<kIssueAB>(ga, ms * HG_ROWS, n0, lds, grp, w_old);
+        };
+        hidden_body<uint8_t, 2, 0, CM>(a.h, ms, ns, lds, nullptr, false, post);
+        if (split) hg_w_item<kIssueA>(ga, ms * HG_ROWS, n0, lds, grp, w_old);
+        if (threadIdx.x == 0) *hdone = round;
+        auto leave = [&](uint32_t code) {  // this workgroup gives up (thread 0 records it)
+            if (threadIdx.x == 0) {
+                chain_give_up(status, code, a.offset, round);
+                if (a.g.n_rows) *a.g.n_rows = -__builtin_inff();   // data-parallel path: every rank skips the update of this step
+            }
+        };
+        if (faulty && a.fault_kind == 2) {   // test hook: as if the barrier had timed out here (the partners get their flag)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (threadIdx.x == 0) __hip_atomic_store(&flags[ms], round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            leave(3u);
+            return;
+        }
+        QBM_STAMP(6);
+        const uint32_t code = hgrad_barrier(flags, ids, ms, nM, round, my_xcc, s_ok);
+        QBM_STAMP(7);
+        if (code != 0u) {
+            leave(code);
+            return;
+        }
+    } else if (a.mode == 1) {              // finishing: the hidden phases the launch of round `round` did not complete
+        if (*hdone == round) return;
+        hidden_body<uint8_t, 2, 0, CM>(a.h, ms, ns, lds);
+        if (threadIdx.x == 0) *hdone = round;
+        return;
+    } else {                               // finishing: the gradient items it did not complete
+        if (*gdone == round) return;
+    }
+
+    // ---- gradient items of this workgroup (every thread of the workgroup takes the same path through them)
+    for (int i = ms; i <= nS; i += nM) {   // the group's items: W items 0 .. nS-1, then the [class rows | hidden bias] tile
+        if (i < nS) {
+            if (split && i == ms) hg_w_item<kConsume>(ga, i * HG_ROWS, n0, lds, grp, w_old);
+            else hg_w_item<kWhole>(ga, i * HG_ROWS, n0, lds, grp, w_old);
+        } else {
+            grad_u_item_par<H_NT, kSc1>(ga, n0, lds, grp);
+        }
+        __syncthreads();                   // the strips exchanged through LDS are consumed: the next item may stage
+    }
+    // items dealt over the groups: visible-bias strips, class bias, loss terms -- to the workgroups with the fewest items
+    const int nBs = ga.nB ? (ga.V + 16 * HG_BMT - 1) / (16 * HG_BMT) : 0, nG = nBs + (ga.nC ? 1 : 0) + (ga.nL ? 1 : 0);
+    for (int t = ns; t < nG; t += nN) {
+        if (ms != nM - 1 - (t / nN) % nM) continue;
+        if (t < nBs) grad_b_item_par<HG_BMT>(ga, t * 16 * HG_BMT, lds, grp);
+        else if (ga.nC && t == nBs) grad_c_item_par(ga, lds, grp);
+        else loss_block(ga, lds);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *gdone = round;
+    QBM_STAMP(13);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1317,14 +1635,22 @@ int panel_for_nq(int K, int reserve)
     return KP < mx ? KP : mx;
 }
 
+// Everything a launch of the hidden conditional needs (also the hidden phase inside k_hgrad)
+struct HiddenPlan {
+    HiddenArgs a;
+    size_t lds;
+    bool fast;
+    int nM, nN;
+};
+
 template <class TA>
-int launch_hidden_t(const qbm_rbm_params* P, const void* v, const float* y, int B, float* p, float* s, uint8_t* s8,
-                    int mode, uint64_t seed, uint64_t offset, uint32_t row0, hipStream_t st, float* pre_out)
+HiddenPlan plan_hidden(const qbm_rbm_params* P, const void* v, const float* y, int B, float* p, float* s, uint8_t* s8, int mode,
+                       uint64_t seed, uint64_t offset, uint32_t row0, float* pre_out, const uint32_t* status)
 {
     constexpr int ASZ = (int)sizeof(TA), MT = H_MT, NT = H_NT, NQ = H_NQ;
     constexpr int kScratch = NQ * 1024;   // one 1 KiB transfer slot per wavefront for the epilogue operands
     HiddenArgs a{v, y, P->W, P->d, P->U, p, s, s8, B, P->V, P->H, P->C, panel_for_nq<MT, NT, ASZ, NQ>(P->V, kScratch), seed,
-                 offset, row0, false, 0, mode == 0 ? pre_out : nullptr};
+                 offset, row0, false, 0, mode == 0 ? pre_out : nullptr, status};
     // LDS-DMA path: whole 16-k pieces, 16-byte aligned units, descriptors below 2 GiB
     const bool fast = (P->V % 16 == 0) && aligned16(v) && (P->H % 4 == 0) && aligned16(P->W) &&
                       small2g((long)B * P->V, ASZ) && small2g((long)P->V * P->H, 4);
@@ -1349,6 +1675,20 @@ int launch_hidden_t(const qbm_rbm_params* P, const void* v, const float* y, int 
         a.ldsCls = (int)lds;
         lds += kScratch;
     }
+    return HiddenPlan{a, lds, fast, nM, nN};
+}
+
+template <class TA>
+int launch_hidden_t(const qbm_rbm_params* P, const void* v, const float* y, int B, float* p, float* s, uint8_t* s8,
+                    int mode, uint64_t seed, uint64_t offset, uint32_t row0, hipStream_t st, float* pre_out,
+                    const uint32_t* status)
+{
+    constexpr int NQ = H_NQ;
+    const HiddenPlan hp = plan_hidden<TA>(P, v, y, B, p, s, s8, mode, seed, offset, row0, pre_out, status);
+    const HiddenArgs& a = hp.a;
+    const size_t lds = hp.lds;
+    const bool fast = hp.fast;
+    const int nM = hp.nM, nN = hp.nN;
 #define QBM_LAUNCH(F, MODE, CM)                                                                      \
     {                                                                                                \
         if (int rc = set_lds(k_hidden<TA, F, MODE, CM>, lds)) return rc;                             \
@@ -1369,16 +1709,18 @@ int launch_hidden_t(const qbm_rbm_params* P, const void* v, const float* y, int 
 }
 
 int launch_hidden(const qbm_rbm_params* P, const void* v, int v_dtype, const float* y, int B, float* p, float* s,
-                  uint8_t* s8, int mode, uint64_t seed, uint64_t offset, uint32_t row0, hipStream_t st, float* pre_out = nullptr)
+                  uint8_t* s8, int mode, uint64_t seed, uint64_t offset, uint32_t row0, hipStream_t st, float* pre_out = nullptr,
+                  const uint32_t* status = nullptr)
 {
-    return v_dtype == QBM_U8 ? launch_hidden_t<uint8_t>(P, v, y, B, p, s, s8, mode, seed, offset, row0, st, pre_out)
-                             : launch_hidden_t<float>(P, v, y, B, p, s, s8, mode, seed, offset, row0, st, pre_out);
+    return v_dtype == QBM_U8 ? launch_hidden_t<uint8_t>(P, v, y, B, p, s, s8, mode, seed, offset, row0, st, pre_out, status)
+                             : launch_hidden_t<float>(P, v, y, B, p, s, s8, mode, seed, offset, row0, st, pre_out, status);
 }
 
 // sample_visible, optionally with the class conditional riding along as aux workgroups
 template <class TA>
 int launch_visible_t(const qbm_rbm_params* P, const void* h, int B, float* p_v, float* v_s, uint8_t* v_s8, float* p_y,
-                     float* y1hot, uint64_t seed, uint64_t offset_v, uint64_t offset_y, uint32_t row0, hipStream_t st)
+                     float* y1hot, uint64_t seed, uint64_t offset_v, uint64_t offset_y, uint32_t row0, hipStream_t st,
+                     const uint32_t* status, uint32_t* hg_round)
 {
     constexpr int ASZ = (int)sizeof(TA), MT = V_MT, NT = V_NT, NQ = V_NQ;
     const bool with_class = p_y || y1hot;
@@ -1387,7 +1729,7 @@ int launch_visible_t(const qbm_rbm_params* P, const void* h, int B, float* p_v, 
                   // pairs of visible units: 8-byte accesses to p / v_f32 / b, 2-byte accesses to v_u8
                   (P->V % 2 == 0) && (!p_v || aligned8(p_v)) && (!v_s || aligned8(v_s)) && (!v_s8 || aligned2(v_s8)) &&
                       aligned8(P->b),
-                  P->U, P->c, p_y, y1hot, P->C, offset_y, with_class ? (B <= 512 ? B : (B + NQ - 1) / NQ) : 0};
+                  P->U, P->c, p_y, y1hot, P->C, offset_y, with_class ? (B <= 512 ? B : (B + NQ - 1) / NQ) : 0, status, status ? hg_round : nullptr};
     const bool fast = (P->H % 16 == 0) && aligned16(h) && aligned16(P->W) && small2g((long)B * P->H, ASZ) &&
                       small2g((long)P->V * P->H, 4);
     const int grid = nM * nN + a.n_aux;
@@ -1408,11 +1750,11 @@ int launch_visible_t(const qbm_rbm_params* P, const void* h, int B, float* p_v, 
 
 int launch_visible(const qbm_rbm_params* P, const void* h, int h_dtype, int B, float* p_v, float* v_s, uint8_t* v_s8,
                    float* p_y, float* y1hot, uint64_t seed, uint64_t offset_v, uint64_t offset_y, uint32_t row0,
-                   hipStream_t st)
+                   hipStream_t st, const uint32_t* status = nullptr, uint32_t* hg_round = nullptr)
 {
     return h_dtype == QBM_U8
-               ? launch_visible_t<uint8_t>(P, h, B, p_v, v_s, v_s8, p_y, y1hot, seed, offset_v, offset_y, row0, st)
-               : launch_visible_t<float>(P, h, B, p_v, v_s, v_s8, p_y, y1hot, seed, offset_v, offset_y, row0, st);
+               ? launch_visible_t<uint8_t>(P, h, B, p_v, v_s, v_s8, p_y, y1hot, seed, offset_v, offset_y, row0, st, status, hg_round)
+               : launch_visible_t<float>(P, h, B, p_v, v_s, v_s8, p_y, y1hot, seed, offset_v, offset_y, row0, st, status, hg_round);
 }
 
 // what the gradient launch of the discriminative step carries besides the strips (kind D workgroups, one phase)
@@ -1436,7 +1778,7 @@ int launch_grad_t(int V, int H, int C, int B, const void* A0, const float* Y0, c
                aux_fused ? aux_fused->U : nullptr, aux_fused ? aux_fused->c : nullptr,
                lr, factor, bs, sparse, B, V, H, C, panel_for<MT, NT, 4>(B),
                nN, want_b ? nM : 0, want_c ? (C + 16 * NT - 1) / (16 * NT) : 0,
-               (H % 4 == 0) && (!G->gW || aligned16(G->gW)) && (!W_fused || aligned16(W_fused)), gU_sub, 0, status, G->n_rows,
+               (H % 4 == 0) && (!G->gW || aligned16(G->gW)) && (!W_fused || aligned16(W_fused)), gU_sub, 0, 0, 0, status, G->n_rows,
                0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (mon_rowloss && mon_loss_acc) { a.nL = 1; a.rowloss = mon_rowloss; a.loss_acc = mon_loss_acc; }
     if (dx) {
@@ -1507,16 +1849,33 @@ int launch_grad(int V, int H, int C, int B, const void* A0, int d0, const float*
 #undef QBM_G
 }
 
-// 0 = never, 1 = where it is faster (default), 2 = whenever the shape allows; initial value from QBM_FUSED_CHAIN
+// 0 = never, 1 = where it is faster (default), 2 = whenever the shape allows, 3 = 1 + the fused tail (k_hgrad) where the shape
+// allows; initial value from QBM_FUSED_CHAIN
 std::atomic<int>& fused_chain_mode_ref()
 {
     static std::atomic<int> mode{[] {
         const char* e = getenv("QBM_FUSED_CHAIN");
-        return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
+        return (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 1;
     }()};
     return mode;
 }
 int fused_chain_mode() { return fused_chain_mode_ref().load(); }
+
+// 8 XCDs x 32 CUs: one workgroup per CU, 32 per XCD -- asked of the device the call runs on, cached per device
+// (0 = not asked yet, 1 = fits, 2 = does not)
+bool device_has_8x32_cus()
+{
+    static std::atomic<signed char> fits_cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    signed char fc = (dev >= 0 && dev < 64) ? fits_cache[dev].load(std::memory_order_relaxed) : (signed char)0;
+    if (fc == 0) {
+        int cus = 0;
+        fc = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus == 256) ? 1 : 2;
+        if (dev >= 0 && dev < 64) fits_cache[dev].store(fc, std::memory_order_relaxed);
+    }
+    return fc == 1;
+}
 
 // The fused chain kernel for the shapes it is written for; QBM_OK + *done = false when the classic sequence of launches
 // has to run instead.
@@ -1525,23 +1884,12 @@ int launch_chain_fused(const qbm_rbm_params* P, const void* v0, int v0_dtype, co
                        hipStream_t st, bool* done)
 {
     *done = false;
-    // 8 XCDs x 32 CUs: one workgroup per CU, 32 per XCD -- asked of the device the call runs on, cached per device
-    // (0 = not asked yet, 1 = fits, 2 = does not)
-    static std::atomic<signed char> fits_cache[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return QBM_OK;
-    signed char fc = (dev >= 0 && dev < 64) ? fits_cache[dev].load(std::memory_order_relaxed) : (signed char)0;
-    if (fc == 0) {
-        int cus = 0;
-        fc = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus == 256) ? 1 : 2;
-        if (dev >= 0 && dev < 64) fits_cache[dev].store(fc, std::memory_order_relaxed);
-    }
-    const bool device_fits = fc == 1;
+    const bool device_fits = device_has_8x32_cus();
     const int mode = fused_chain_mode();
     // mode 1: where it is faster -- from two Gibbs iterations on (CD-1: the first hidden phase of the fused kernel streams all
     // of W into every XCD, 12.8 MB instead of 1.6, which costs what the two saved launch boundaries gain; measured
     // 30.0 vs 29.9 us per step; PCD-10: 136 vs 160)
-    const bool enabled = device_fits && (mode == 2 || (mode == 1 && k >= 2));
+    const bool enabled = device_fits && (mode == 2 || ((mode == 1 || mode == 3) && k >= 2));
     if (!enabled || !ws->sync || v0_dtype != QBM_U8) return QBM_OK;
     const int V = P->V, H = P->H, C = P->C;
     if (B % 32 != 0 || B > 256 || H % 16 != 0 || H > 512 || V % 16 != 0 || V > 1024 || 5 * C + 4 > 64) return QBM_OK;
@@ -1574,6 +1922,84 @@ int launch_chain_fused(const qbm_rbm_params* P, const void* v0, int v0_dtype, co
     return QBM_OK;
 }
 
+// test hook (qbm_test_hgrad_fault): the next k_hgrad launch of mode 0 makes one workgroup misbehave
+std::atomic<int> g_hgrad_fault_wg{-1}, g_hgrad_fault_kind{0};
+
+// Can the tail of this CD step -- last hidden phase + gradient (+ update) -- be ONE launch (k_hgrad)?
+bool hgrad_eligible(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void* v0, int v0_dtype, const float* y0, int B,
+                    const uint8_t* v1, const float* y1, const qbm_rbm_cd_workspace* ws, int fuse_update)
+{
+    // mode 3 only: measured slower than the launch-per-phase tail on every shape tried -- kept as an
+    // opt-in, with its tests, next to the numbers that say why
+    if (fused_chain_mode() != 3 || !device_has_8x32_cus() || !ws || !ws->sync || v0_dtype != QBM_U8) return false;
+    const int V = P->V, H = P->H, C = P->C;
+    const int nM = (B + 16 * H_MT - 1) / (16 * H_MT), nN = (H + 16 * H_NT - 1) / (16 * H_NT);
+    // (B <= 256: one panel of 64 rows per K chain of the gradient -- its operands are requested in one go under the hidden phase)
+    if (B <= 0 || B > 256 || B % 16 != 0 || H % 16 != 0 || V % 16 != 0 || nN % 8 != 0 || nN > 32 || nM * nN > 256) return false;
+    if (5 * C + 4 > 64 || ((long)B * C) % 4 != 0 || C + 1 > 16) return false;
+    const void* ptrs[] = {v0, y0, v1, y1, P->W, P->d, P->U, ws->ph0, ws->phk, G->gW};
+    for (const void* q : ptrs)
+        if (q && !aligned16(q)) return false;
+    if (!small2g((long)B * V, 4) || !small2g((long)V * H, 4) || !small2g((long)B * H, 4)) return false;
+    (void)fuse_update;
+    // the hidden phase on its all-DMA path, and room behind it for the operands of the gradient's phase 0 (launch_hgrad)
+    const HiddenPlan hp = plan_hidden<uint8_t>(P, v1, y1, B, ws->phk, nullptr, nullptr, 0, 0, 0, 0, nullptr, nullptr);
+    if (!hp.fast || !hp.a.epiDma) return false;
+    const size_t area = 2 * 4 * (size_t)strip_wave_bytes_a<HG_MT, H_NT, 1>(64) + 4 * (size_t)strip_wave_bytes_b<H_NT>(64);
+    return (hp.lds > area + 16 ? hp.lds : area + 16) + area <= 163840;
+}
+
+// mode 0: the step's tail; 1 / 2: finishing a step whose launch of round `round` gave up (qbm_rbm_cd_step_finish)
+int launch_hgrad(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void* v0, const float* y0, int B, uint64_t seed,
+                 uint64_t offset, uint64_t off_h, uint32_t row0, const uint8_t* v1, const float* y1, const qbm_rbm_cd_workspace* ws,
+                 int fuse_update, float lr, float factor, float bs, float sparse, const float* mon_rowloss, double* mon_loss_acc,
+                 hipStream_t st, int mode, uint32_t round)
+{
+    const int V = P->V, H = P->H, C = P->C;
+    HiddenPlan hp = plan_hidden<uint8_t>(P, v1, y1, B, ws->phk, nullptr, nullptr, 0, seed, off_h, row0, nullptr, nullptr);
+    if (!hp.fast || !hp.a.epiDma) return fail(QBM_ERR_ARG, "cd_step: fused tail launched on a shape it does not take");
+    qbm_rbm_grads g = *G;
+    if (fuse_update) g.gW = nullptr;   // the whole update happens inside the launch
+    const bool want_b = g.gb || fuse_update, want_c = g.gc || fuse_update;
+    GradArgs ga{v0, y0, ws->ph0, v1, y1, ws->phk, g.gW, g.gb, g.gd, g.gU, g.gc, fuse_update ? P->W : nullptr,
+                fuse_update ? P->b : nullptr, fuse_update ? P->d : nullptr, fuse_update ? P->U : nullptr,
+                fuse_update ? P->c : nullptr, lr, factor, bs, sparse, B, V, H, C, 64,
+                0, want_b ? 1 : 0, want_c ? 1 : 0,
+                (H % 4 == 0) && (!g.gW || aligned16(g.gW)) && aligned16(P->W), nullptr, 0, 0, 0, nullptr, G->n_rows,
+                0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (mon_rowloss && mon_loss_acc) { ga.nL = 1; ga.rowloss = mon_rowloss; ga.loss_acc = mon_loss_acc; }
+    // LDS.  Items that go in one call: a staging region per thread group, sized for the largest kind (see launch_grad_t).
+    size_t grp = strip_lds_bytes<HG_MT, H_NT, 1>(ga.KP);
+    if (grp < (size_t)strip_lds_bytes<1, H_NT, 4>(ga.KP)) grp = strip_lds_bytes<1, H_NT, 4>(ga.KP);
+    if (grp < (size_t)strip_lds_bytes<HG_BMT, 1, 1>(ga.KP)) grp = strip_lds_bytes<HG_BMT, 1, 1>(ga.KP);
+    ga.lds_group = (int)grp;
+    // The W item in several calls (hg_w_item): [A tiles of thread group 0 | of group 1 | the P panel] per phase -- phase 1 at
+    // the front (the hidden phase's staging area, dead by then), the barrier's result word behind it, phase 0 behind
+    // everything the hidden phase uses.
+    const size_t area = 2 * 4 * (size_t)strip_wave_bytes_a<HG_MT, H_NT, 1>(ga.KP) + 4 * (size_t)strip_wave_bytes_b<H_NT>(ga.KP);
+    ga.lds_sok = (int)area;
+    ga.lds_group0 = (int)(hp.lds > area + 16 ? hp.lds : area + 16);
+    size_t lds = ga.lds_group0 + area;
+    if (lds < 2 * grp) lds = 2 * grp;
+    if (lds < 2 * 2 * 256 * sizeof(float4)) lds = 2 * 2 * 256 * sizeof(float4);   // the strips the groups exchange (small items)
+    if (lds < 24576) lds = 24576;                                                  // the loss terms' arrays
+    if (lds > 163840) return fail(QBM_ERR_ARG, "cd_step: LDS budget of the fused tail exceeded");
+    HGradArgs a{hp.a, ga, ws->sync, offset, mode, round, -1, 0};
+    if (mode == 0) {
+        a.fault_wg = g_hgrad_fault_wg.exchange(-1);
+        a.fault_kind = g_hgrad_fault_kind.load();
+    }
+#define QBM_L(CM)                                                                          \
+    {                                                                                      \
+        if (int rc = set_lds(k_hgrad<CM>, lds)) return rc;                                 \
+        hipLaunchKernelGGL((k_hgrad<CM>), dim3(hp.nM * hp.nN), dim3(512), lds, st, a);     \
+    }
+    QBM_DISPATCH_CM(C, QBM_L);
+#undef QBM_L
+    QBM_CHECK_LAUNCH("k_hgrad");
+    return QBM_OK;
+}
+
 
 }  // namespace
 
@@ -1584,7 +2010,7 @@ extern "C" {
 
 int qbm_rbm_fused_chain_mode(int mode)
 {
-    if (mode < 0 || mode > 2) return fused_chain_mode();
+    if (mode < 0 || mode > 3) return fused_chain_mode();
     return fused_chain_mode_ref().exchange(mode);
 }
 
@@ -1669,7 +2095,7 @@ int qbm_rbm_free_energy(const qbm_rbm_params* P, const float* x, int B, float* p
 #define QBM_L(CM)                                                                                               \
     hipLaunchKernelGGL((k_free_energy<CM>), dim3(B), dim3(64 * P->C), 0, (hipStream_t)stream, pre_ws, P->U,             \
                        P->c, neg_free_energy, p_y_given_x, B, P->H, P->C, (const int*)nullptr, (float*)nullptr,   \
-                       (float*)nullptr)
+                       (float*)nullptr, (const uint32_t*)nullptr)
     QBM_DISPATCH_CM(P->C, QBM_L);
 #undef QBM_L
     QBM_CHECK_LAUNCH("k_free_energy");
@@ -1724,9 +2150,12 @@ int qbm_f32_to_u8(const float* x, uint8_t* y, long n, void* stream)
     return QBM_OK;
 }
 
+// defer_last: the caller runs the last hidden phase itself (fused with the gradient: k_hgrad) -- unless the one-launch chain
+// takes the step (*fused); hg_status: status word every launch tests (HiddenArgs::status), or null
 static int cd_chain_impl(const qbm_rbm_params* P, const void* v0, int v0_dtype, const float* y0, int B, int k, uint64_t seed,
                          uint64_t offset, uint32_t row0, uint8_t* chain_v, float* chain_y, const qbm_rbm_cd_workspace* ws,
-                         void* stream, bool* fused, float* mon_pre = nullptr)
+                         void* stream, bool* fused, float* mon_pre = nullptr, bool defer_last = false,
+                         const uint32_t* hg_status = nullptr)
 {
     *fused = false;
     if (int rc = check_params(P)) return rc;
@@ -1746,10 +2175,10 @@ static int cd_chain_impl(const qbm_rbm_params* P, const void* v0, int v0_dtype, 
     // (mon_pre: the training loop's monitor wants v0.W + d -- one more store of the positive-phase launch)
     if (chain_v) {
         // positive phase on the data (probabilities only), negative chain from the persistent state
-        if (int rc = launch_hidden(P, v0, v0_dtype, y0, B, ws->ph0, nullptr, nullptr, 0, seed, offset, row0, st, mon_pre)) return rc;
-        if (int rc = launch_hidden(P, chain_v, QBM_U8, chain_y, B, nullptr, nullptr, ws->h, 0, seed, offset, row0, st)) return rc;
+        if (int rc = launch_hidden(P, v0, v0_dtype, y0, B, ws->ph0, nullptr, nullptr, 0, seed, offset, row0, st, mon_pre, hg_status)) return rc;
+        if (int rc = launch_hidden(P, chain_v, QBM_U8, chain_y, B, nullptr, nullptr, ws->h, 0, seed, offset, row0, st, nullptr, hg_status)) return rc;
     } else {
-        if (int rc = launch_hidden(P, v0, v0_dtype, y0, B, ws->ph0, nullptr, ws->h, 0, seed, offset, row0, st, mon_pre)) return rc;
+        if (int rc = launch_hidden(P, v0, v0_dtype, y0, B, ws->ph0, nullptr, ws->h, 0, seed, offset, row0, st, mon_pre, hg_status)) return rc;
     }
     for (int t = 1; t <= k; ++t) {
         const uint64_t o = offset + 3ull * (uint64_t)t;
@@ -1757,10 +2186,12 @@ static int cd_chain_impl(const qbm_rbm_params* P, const void* v0, int v0_dtype, 
         uint8_t* v_out = (chain_v && t == k) ? chain_v : ws->vk;
         float* y_out = (chain_v && t == k) ? chain_y : ws->yk;
         // v_t and y_t both depend on h_{t-1} only: one launch (class conditional as aux workgroups)
-        if (int rc = launch_visible(P, ws->h, QBM_U8, B, nullptr, nullptr, v_out, nullptr, y_out, seed, o - 2, o - 1, row0, st))
+        if (int rc = launch_visible(P, ws->h, QBM_U8, B, nullptr, nullptr, v_out, nullptr, y_out, seed, o - 2, o - 1, row0, st, hg_status,
+                                    (t == k && defer_last) ? ws->sync + kHgRound : nullptr))
             return rc;
+        if (t == k && defer_last) break;
         // the hidden SAMPLE of the last iteration has no consumer (the gradient uses p(h_k)): no draw, no store
-        if (int rc = launch_hidden(P, v_out, QBM_U8, y_out, B, ws->phk, nullptr, t < k ? ws->h : nullptr, 0, seed, o, row0, st))
+        if (int rc = launch_hidden(P, v_out, QBM_U8, y_out, B, ws->phk, nullptr, t < k ? ws->h : nullptr, 0, seed, o, row0, st, nullptr, hg_status))
             return rc;
     }
     return QBM_OK;
@@ -1782,12 +2213,21 @@ int qbm_rbm_cd_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void*
     if (!G) return fail(QBM_ERR_ARG, "cd_step: grads is null");
     if (!fuse_update && (!G->gW || !G->gb || !G->gd || !G->gU || !G->gc))
         return fail(QBM_ERR_ARG, "cd_step: all gradient blocks are required without fuse_update");
+    if (int rc = check_params(P)) return rc;
     bool fused = false;
     // the training loop's monitor (ws->mon_*): p(y|x0) under the parameters BEFORE this step's update (what
     // discriminative_training reports too, src/ClassificationRBM.py:108, :142) and its two loss terms
     const bool mon = ws && ws->mon_labels && ws->mon_pre && ws->mon_p && ws->mon_rowloss && ws->mon_loss_acc;
+    // The tail of the step -- last hidden phase, gradient, update -- as ONE launch (k_hgrad) where the shape allows; every
+    // launch of the step then tests the workspace's status word (a fused tail that gave up is FINISHED by the host, from
+    // the workspace as that step left it: qbm_rbm_cd_step_finish)
+    const uint8_t* v1 = (ws && chain_v) ? chain_v : (ws ? ws->vk : nullptr);
+    const float* y1 = (ws && chain_y) ? chain_y : (ws ? ws->yk : nullptr);
+    const bool hg = B > 0 && batch_size > 0.f && v0 && y0 && ws && ws->ph0 && ws->phk && v1 && y1 &&
+                    hgrad_eligible(P, G, v0, v0_dtype, y0, B, v1, y1, ws, fuse_update);
+    const uint32_t* hg_status = hg ? ws->sync + 512 : nullptr;
     if (int rc = cd_chain_impl(P, v0, v0_dtype, y0, B, k, seed, offset, row0, chain_v, chain_y, ws, stream, &fused,
-                               mon ? ws->mon_pre : nullptr))
+                               mon ? ws->mon_pre : nullptr, hg, hg_status))
         return rc;
     if (B == 0) return zero_grads(P, G, (hipStream_t)stream);
     if (!(batch_size > 0.f)) return fail(QBM_ERR_ARG, "cd_step: batch_size must be positive");
@@ -1798,11 +2238,15 @@ int qbm_rbm_cd_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void*
             if (int rc = launch_hidden(P, v0, v0_dtype, nullptr, B, ws->mon_pre, nullptr, nullptr, 1, 0, 0, 0, st)) return rc;
 #define QBM_L(CM)                                                                                                         \
     hipLaunchKernelGGL((k_free_energy<CM>), dim3(B), dim3(64 * P->C), 0, st, ws->mon_pre, P->U, P->c, (float*)nullptr, ws->mon_p, \
-                       B, P->H, P->C, ws->mon_labels, (float*)nullptr, ws->mon_rowloss)
+                       B, P->H, P->C, ws->mon_labels, (float*)nullptr, ws->mon_rowloss, hg_status)
         QBM_DISPATCH_CM(P->C, QBM_L);
 #undef QBM_L
         QBM_CHECK_LAUNCH("k_free_energy");
     }
+    if (hg && !fused)
+        return launch_hgrad(P, G, v0, y0, B, seed, offset, offset + 3ull * (uint64_t)k, row0, v1, y1, ws, fuse_update, lr, factor,
+                            batch_size, sparse_constant, mon ? ws->mon_rowloss : nullptr, mon ? ws->mon_loss_acc : nullptr,
+                            (hipStream_t)stream, 0, 0u);
     qbm_rbm_grads g = *G;
     if (fuse_update) g.gW = nullptr;  // the whole update happens inside the gradient launch
     // PCD: (v_k, y_k) live in the persistent chains.  Behind the one-launch chain the gradient launch reads the chain's status
@@ -1811,6 +2255,51 @@ int qbm_rbm_cd_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void*
                        chain_v ? chain_y : ws->yk, ws->phk, &g, fuse_update ? P->W : nullptr, fuse_update ? P : nullptr, lr,
                        factor, batch_size, sparse_constant, (hipStream_t)stream, nullptr, fused ? ws->sync + 512 : nullptr, nullptr,
                        mon ? ws->mon_rowloss : nullptr, mon ? ws->mon_loss_acc : nullptr);
+}
+
+int qbm_rbm_cd_step_finish(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void* v0, int v0_dtype, const float* y0, int B,
+                           int k, uint64_t seed, uint64_t offset, uint32_t row0, uint8_t* chain_v, float* chain_y,
+                           const qbm_rbm_cd_workspace* ws, int fuse_update, float lr, float factor, float batch_size,
+                           float sparse_constant, uint32_t round, void* stream)
+{
+    if (!G || !ws) return fail(QBM_ERR_ARG, "cd_step_finish: null argument");
+    if (int rc = check_params(P)) return rc;
+    if (k < 1 || B <= 0 || !(batch_size > 0.f)) return fail(QBM_ERR_ARG, "cd_step_finish: bad k / B / batch_size");
+    const uint8_t* v1 = chain_v ? chain_v : ws->vk;
+    const float* y1 = chain_y ? chain_y : ws->yk;
+    const int prev = fused_chain_mode_ref().exchange(3);   // (eligibility is asked as the step asked it: the switch may be off by now)
+    const bool hg = v0 && y0 && ws->ph0 && ws->phk && v1 && y1 && hgrad_eligible(P, G, v0, v0_dtype, y0, B, v1, y1, ws, fuse_update);
+    fused_chain_mode_ref().store(prev);
+    if (!hg) return fail(QBM_ERR_ARG, "cd_step_finish: not a step the fused tail takes");
+    const bool mon = ws->mon_labels && ws->mon_pre && ws->mon_p && ws->mon_rowloss && ws->mon_loss_acc;
+    for (int mode = 1; mode <= 2; ++mode)
+        if (int rc = launch_hgrad(P, G, v0, y0, B, seed, offset, offset + 3ull * (uint64_t)k, row0, v1, y1, ws, fuse_update, lr,
+                                  factor, batch_size, sparse_constant, mon ? ws->mon_rowloss : nullptr,
+                                  mon ? ws->mon_loss_acc : nullptr, (hipStream_t)stream, mode, round))
+            return rc;
+    return QBM_OK;
+}
+
+int qbm_rbm_cd_tail(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void* v0, int v0_dtype, const float* y0, int B,
+                    const uint8_t* vk, const float* yk, const qbm_rbm_cd_workspace* ws, int fuse_update, float lr, float factor,
+                    float batch_size, float sparse_constant, uint32_t round, void* stream)
+{
+    if (!G || !ws) return fail(QBM_ERR_ARG, "cd_tail: null argument");
+    if (int rc = check_params(P)) return rc;
+    if (!fuse_update && (!G->gW || !G->gb || !G->gd || !G->gU || !G->gc))
+        return fail(QBM_ERR_ARG, "cd_tail: all gradient blocks are required without fuse_update");
+    if (round == 0u || B <= 0 || !(batch_size > 0.f)) return fail(QBM_ERR_ARG, "cd_tail: bad round / B / batch_size");
+    if (!(v0 && y0 && vk && yk && ws->ph0 && ws->phk && hgrad_eligible(P, G, v0, v0_dtype, y0, B, vk, yk, ws, fuse_update)))
+        return fail(QBM_ERR_ARG, "cd_tail: not a shape the fused tail takes (or qbm_rbm_fused_chain_mode is 0)");
+    return launch_hgrad(P, G, v0, y0, B, 0, 0, 0, 0, vk, yk, ws, fuse_update, lr, factor, batch_size, sparse_constant, nullptr,
+                        nullptr, (hipStream_t)stream, 0, round);
+}
+
+int qbm_test_hgrad_fault(int workgroup, int kind)
+{
+    g_hgrad_fault_kind.store(kind);
+    g_hgrad_fault_wg.store(workgroup);
+    return QBM_OK;
 }
 
 int qbm_rbm_disc_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const float* x, const int32_t* labels, int B,
@@ -1845,7 +2334,7 @@ int qbm_rbm_disc_step_ex(const qbm_rbm_params* P, const qbm_rbm_grads* G, const 
     if (int rc = launch_hidden(P, x, x_dtype, nullptr, B, ws->pre, nullptr, nullptr, 1, 0, 0, 0, st)) return rc;
 #define QBM_L(CM)                                                                                               \
     hipLaunchKernelGGL((k_free_energy<CM>), dim3(B), dim3(64 * P->C), 0, st, ws->pre, P->U, P->c, neg_free_energy, p_y, \
-                       B, P->H, P->C, labels, ws->diff, ws->rowloss)
+                       B, P->H, P->C, labels, ws->diff, ws->rowloss, (const uint32_t*)nullptr)
     QBM_DISPATCH_CM(P->C, QBM_L);
 #undef QBM_L
     QBM_CHECK_LAUNCH("k_free_energy");

@@ -225,11 +225,16 @@ struct ViewCContigU8 {
         return DmaLane{c0 < cols ? (unsigned)(k * (int)ld + c0) : kOOB, (unsigned)(64 * ld), k, 64};
     }
     // transfer instruction j (0..TILES-1) of a quad, all TILES adjacent 16-wide tiles from column c0 on: lane L takes
-    // k = kb + (64/TILES)*j + L/TILES of tile L % TILES
+    // k = kb + (64/TILES)*j + L/TILES of tile L % TILES.  TILES == 8: a k row is 128 bytes, so the rows k and k + 1 that
+    // the lane groups g and g + 1 of a ds_read_u8 read (one 32-lane banking group) would meet on the same banks; odd k
+    // rows are therefore stored with their tiles 0-3 and 4-7 swapped (slot tile ^ 4): a per-lane SOURCE address here, a
+    // per-lane constant in the fragment address (strip_mma: fragA / adA) -- conflict-free like the 4-tile image.
     template <int TILES>
     __device__ __forceinline__ DmaLane lane0_tiles(int c0, int kb, int lane, int j) const
     {
-        const int k = kb + (64 / TILES) * j + lane / TILES, c = c0 + 16 * (lane % TILES);
+        const int kl = lane / TILES;
+        const int tile = TILES == 8 ? ((lane % TILES) ^ ((kl & 1) << 2)) : lane % TILES;
+        const int k = kb + (64 / TILES) * j + kl, c = c0 + 16 * tile;
         return DmaLane{c < cols ? (unsigned)(k * (int)ld + c) : kOOB, (unsigned)(64 * ld), k, 64};
     }
     __device__ __forceinline__ uint4 get(int c0, int kb, int kend, int slot) const
@@ -405,20 +410,41 @@ __device__ __forceinline__ void vm_wait(int n)
 // ADJACENT in a K-contiguous image: one ds_read_b32 (u8: + v_cvt_f32_ubyte0..3) or one ds_read_b128 (fp32) per tile and
 // piece instead of four byte reads / two ds_read2st64; a row-per-k fp32 image is filled with its rows permuted (a per-lane
 // source address, free) and read as before.
-// AUX_A: cache policy of the A operand's transfers (kSc1 inside the fused Gibbs chain, where A is a state another workgroup
-// of the XCD has just written; FAST_A only).
-template <int MT, int NT, bool FAST_A, bool FAST_B, int CPT = 4, int NQ = 4, bool KPERM = false, int AUX_A = 0, class AView,
-          class BView, class Pre0 = NoPre, class Pre = NoPre>
+// AUX_A / AUX_B: cache policy of the A / B operand's transfers (kSc1 where the operand is a state another workgroup of the
+// XCD has written during this launch: the fused Gibbs chain's A operands, the p(h_k) panel of the fused hidden + gradient
+// launch; LDS-DMA operands only).
+// PHASE: the contraction in two calls, around other work of the wavefront (k_hgrad: the gradient's operands are requested
+// under the tail of the hidden phase and contracted behind the barrier).  LDS-DMA operands, ONE panel per chain (KP >= the
+// chain length, at most 60 transfer instructions):
+//   kIssueAB / kIssueA  request all of the chain's A and B (only A) transfers, call pre0(), return (the result is unspecified);
+//   kIssueB  request the B transfers of a chain whose A transfers are out already, return;
+//   kConsume / kIssueBConsume  (request the B transfers,) wait until at most `younger` of this wavefront's transfers are in
+//   flight (those requested AFTER this chain's: the caller counts them, chain_transfers_b below), contract, combine.
+// `post()`: called once between the contraction and the combine (every transfer of this call has been consumed).
+constexpr int kWhole = 0, kIssueAB = 1, kConsume = 2, kIssueA = 3, kIssueBConsume = 4, kIssueB = 5;
+// B transfers one wavefront issues for its chain of a K-long contraction in the two-call form (one panel)
+template <int NT, int NQ = 4>
+__device__ __forceinline__ int chain_transfers_b(int K, int KP)
+{
+    const int q = __builtin_amdgcn_readfirstlane(((int)threadIdx.x & (64 * NQ - 1)) >> 6);
+    const int Kq = chain_len(K, NQ), klen = max(0, min(min(K, (q + 1) * Kq) - q * Kq, KP));
+    return NT * ((klen + 15) >> 4);
+}
+template <int MT, int NT, bool FAST_A, bool FAST_B, int CPT = 4, int NQ = 4, bool KPERM = false, int AUX_A = 0, int AUX_B = 0,
+          int PHASE = kWhole, class AView, class BView, class Pre0 = NoPre, class Pre = NoPre, class Post = NoPre>
 __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView& A, const BView& Bv, int m0, int n0, int K,
                                                                     char* __restrict__ lds, int KP, Pre0&& pre0 = NoPre{},
                                                                     Pre&& pre = NoPre{}, int stamp0 = 0,
-                                                                    char* __restrict__ ldsB = nullptr, bool b_resident = false)
+                                                                    char* __restrict__ ldsB = nullptr, bool b_resident = false,
+                                                                    Post&& post = NoPre{}, int younger = 0)
 {
+    static_assert(PHASE == kWhole || (FAST_A && FAST_B), "the two-call form takes LDS-DMA operands");
     // ldsB != nullptr: the B images live in a region of their own (NQ * strip_wave_bytes_b<NT>(KP) bytes) instead of behind
     // each wave's A tiles; b_resident: they are already there (the caller ran this very contraction's B operand through
     // this function before, with one panel per chain, and nothing has overwritten the region): no B transfers are issued.
     static_assert(NQ == 4 || NQ == 8, "4 or 8 chains");
     static_assert(AUX_A == 0 || FAST_A, "a cache policy only applies to LDS-DMA transfers");
+    static_assert(AUX_B == 0 || FAST_B, "a cache policy only applies to LDS-DMA transfers");
     (void)stamp0;   // first stamp slot of this call (diagnostic builds only)
     using TA = typename AView::elem;
     const int qbm_diag = QBM_DIAG_MODE;   // 0 in the product: the diagnostic branches fold away
@@ -562,7 +588,11 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
         using std::integral_constant;
         uint32_t adA[MT], adB[NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) adA[i] = lds_off(imgA) + (uint32_t)(fragA + i * a_tile + qd * 4 * kPieceA);
+        for (int i = 0; i < MT; ++i) {
+            // (8-tile u8 lin image: odd k rows hold their tiles 0-3 / 4-7 swapped, and k = 4s + g is odd with g: lane0_tiles)
+            const int ti = (A_TILES && MT == 8) ? (i ^ (((lane >> 4) & 1) << 2)) : i;
+            adA[i] = lds_off(imgA) + (uint32_t)(fragA + ti * a_tile + qd * 4 * kPieceA);
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) adB[t] = lds_off(imgB) + (uint32_t)(fragB + t * b_tile + qd * 4096);
         auto reads1 = [&](auto PC, Frag& f) {   // chunk 1: at most 15 reads
@@ -634,9 +664,10 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
         };
         auto quad_pieces = [&](int qd) { return min(4, pieces - 4 * qd); };
         auto quad_dmas = [&](int qd) { return qd < quads ? (A8 ? MT : MT * quad_pieces(qd)) + nt_dma * quad_pieces(qd) : 0; };
-        auto issue_quad = [&](int qd) {
+        auto issue_quad = [&](int qd, bool do_a = true, bool do_b = true) {
             const int np = quad_pieces(qd);
             if constexpr (A8) {
+                if (do_a)
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     // u8: one instruction covers the 4 pieces (k4 image: of its tile; lin image: a (64/MT)-k slice of
@@ -648,16 +679,17 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
             }
             for (int pc = 4 * qd; pc < 4 * qd + np; ++pc) {
                 if constexpr (!A8) {
+                    if (do_a)
 #pragma unroll
                     for (int i = 0; i < MT; ++i) {
                         blds16<AUX_A>(ra, la[i].voff, imgA + i * a_tile + pc * 1024);
                         la[i].voff += la[i].step;
                     }
                 }
-                if (!b_resident) {
+                if (!b_resident && do_b) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
-                        blds16(rb, lb[t].voff, imgB + t * b_tile + pc * 1024);
+                        blds16<AUX_B>(rb, lb[t].voff, imgB + t * b_tile + pc * 1024);
                         lb[t].voff += lb[t].step;
                     }
                 }
@@ -666,6 +698,23 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
         // How far the requests run ahead of the quad being contracted: 1 = the next quad is requested when the current one
         // has landed, 2 = two quads in flight.
         open_panel(kq0);
+        if constexpr (PHASE != kWhole) {
+            // the two-call form: everything of the (single) panel is requested at once, everything is awaited at once
+            if constexpr (PHASE == kIssueAB || PHASE == kIssueA || PHASE == kIssueB) {
+                for (int qd = 0; qd < quads; ++qd) issue_quad(qd, PHASE != kIssueB, PHASE != kIssueA);
+                pre0();
+                QBM_STAMP(stamp0 + 1);
+                return StripOut<MT, NT, CPT, 64 * NQ>{};
+            } else {
+                if constexpr (PHASE == kIssueBConsume)
+                    for (int qd = 0; qd < quads; ++qd) issue_quad(qd, false, true);
+                QBM_STAMP(stamp0 + 1);
+                vm_wait(younger);
+                QBM_STAMP(stamp0 + 2);
+                run(0, pieces);
+                QBM_STAMP(stamp0 + 3);
+            }
+        } else {
         const int ahead = QBM_DMA_AHEAD > 0 ? QBM_DMA_AHEAD : (quads <= 2 ? 1 : 2);
         if (qbm_diag != 4 && quads > 0) issue_quad(0);
         pre0();
@@ -697,6 +746,7 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
             }
             QBM_STAMP(stamp0 + 3);
         }
+        }   // PHASE == kWhole
     } else {
         // ---- at least one operand goes through registers (unaligned / ragged / synthesised)
         pre0();
@@ -723,7 +773,8 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
 #pragma unroll
                     for (int i = 0; i < MT; ++i) {
                         const uint4 v = view_get<KPERM>(A, m0 + 16 * i, kb, kend, g * 64 + lane);
-                        if constexpr (A_TILES) reinterpret_cast<uint4*>(imgA)[(g * 64 + lane) * MT + i] = v;   // slot k*MT + tile
+                        if constexpr (A_TILES)   // slot k*MT + tile (8 tiles: odd k rows swap their halves, see lane0_tiles)
+                            reinterpret_cast<uint4*>(imgA)[(g * 64 + lane) * MT + (MT == 8 ? (i ^ ((lane & 1) << 2)) : i)] = v;
                         else reinterpret_cast<uint4*>(imgA + i * a_tile)[g * 64 + lane] = v;
                     }
             } else {
@@ -738,7 +789,7 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
                 for (int t = 0; t < NT; ++t) {
                     DmaLane lb = view_lane0<KPERM>(Bv, n0 + 16 * t, kb, lane);
                     for (int pc = 0; pc < pieces; ++pc) {
-                        blds16(rb, lb.voff, imgB + t * b_tile + pc * 1024);
+                        blds16<AUX_B>(rb, lb.voff, imgB + t * b_tile + pc * 1024);
                         lb.voff += lb.step;
                     }
                 }
@@ -756,6 +807,7 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
         }
     }
 
+    post();
     // partial strips -> LDS (each wave reuses the head of its own staging region), row-major
     // [16*MT][RS], RS = 16*NT + 4 (the +4 keeps lanes l and l+16, four rows apart, on different banks)
     constexpr int RS = 16 * NT + 4;
@@ -766,7 +818,14 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[(16 * i + (lane >> 4) * 4 + r) * RS + 16 * t + (lane & 15)] = acc[i][t][r];
-    __syncthreads();
+    // A `post` hook may have put transfers in flight that are to land under what follows: the workgroup barriers of the
+    // combine then order LDS accesses only (__syncthreads makes the compiler drain vmcnt as well)
+    constexpr bool kKeepVm = !std::is_same<std::decay_t<Post>, NoPre>::value;
+    auto wg_barrier = [&]() {
+        if constexpr (kKeepVm) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else __syncthreads();
+    };
+    wg_barrier();
 
     StripOut<MT, NT, CPT, 64 * NQ> o;
 #pragma unroll
@@ -800,7 +859,7 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
         }
     }
     QBM_STAMP(stamp0 + 4);
-    __syncthreads();  // the partials are consumed: the caller may run another contraction on this LDS
+    wg_barrier();  // the partials are consumed: the caller may run another contraction on this LDS
     return o;
 }
 

@@ -251,11 +251,21 @@ class HipRbmOps:
                                        seed, offset, row0, ptr(chain_v), ptr(chain_y), C.byref(cws), int(fuse), lr, factor,
                                        batch_size, sparse, current_stream()), "qbm_rbm_cd_step")
         if own_ws and ws[5] is not None and self._may_fuse(k, vd):
-            # the one-launch chain may have run: keep what it takes to repeat the step on the launch-per-phase path, until the
-            # next look at the status word (check_chain_status: end of an epoch, or every kPendingMax steps)
+            # a launch that synchronises workgroups inside an XCD may have run (the one-launch chain, or the fused tail: last
+            # hidden phase + gradient + update): keep what it takes to repeat the step on the launch-per-phase path -- and, for
+            # a fused tail with the update inside, to FINISH it (qbm_rbm_cd_step_finish: part of the update may have been
+            # applied) -- until the next look at the status word (check_chain_status: end of an epoch, or every kPendingMax steps)
             args = (P, G, v0, y0, k, seed, offset, row0, chain_v, chain_y, fuse, lr, factor, batch_size, sparse)
+            pst, gst = P.struct(), G.struct(with_count=with_count)
+
+            def finish(rnd):
+                check(self.lib.qbm_rbm_cd_step_finish(C.byref(pst), C.byref(gst), ptr(v0), vd, ptr(y0), B, k, seed, offset, row0,
+                                                      ptr(chain_v), ptr(chain_y), C.byref(cws), int(fuse), lr, factor, batch_size,
+                                                      sparse, rnd, current_stream()), "qbm_rbm_cd_step_finish")
+
             self._pending.append((int(offset) & 0xFFFFFFFF, replay if replay is not None else
-                                  (lambda: self.cd_step(*args, with_count=with_count, monitor=monitor))))
+                                  (lambda: self.cd_step(*args, with_count=with_count, monitor=monitor)),
+                                  finish if fuse else None))
         if chain_v is not None:   # PCD: the k-th iteration wrote straight into the chains
             return (ws[0], ws[1], chain_v, chain_y, ws[4])
         return ws[:6]
@@ -268,7 +278,8 @@ class HipRbmOps:
         shape as well) and independent of the row count, so that the ranks of a data-parallel group -- whose shards of a short
         last minibatch differ -- record the same steps and look at the status word at the same steps."""
         mode = int(self.lib.qbm_rbm_fused_chain_mode(-1))   # process-wide switch: asked, not cached
-        return v_dtype == QBM_U8 and (mode == 2 or (mode == 1 and k >= 2))
+        # (modes 1, 3 from k = 2 on and mode 2: the one-launch chain; mode 3 otherwise: the fused tail of the step)
+        return v_dtype == QBM_U8 and (mode >= 2 or (mode == 1 and k >= 2))
 
     def _sync_buffer(self):
         """ONE state buffer of the fused chain kernel per HipRbmOps (= per stream of work): it outlives the workspaces, which
@@ -297,50 +308,62 @@ class HipRbmOps:
                 f(P.H, torch.float32), sync)  # ph0, h, vk, yk, phk, state of the fused chain kernel
 
     def fused_chain_mode(self, mode=-1):
-        """0 = never use the one-launch chain kernel, 1 = where it is faster (k >= 2; default), 2 = whenever the shape allows;
-        -> previous mode (no argument: query).  Process-wide (include/qbm_hip.h: qbm_rbm_fused_chain_mode)."""
+        """0 = never use the one-launch chain kernel, 1 = where it is faster (k >= 2; default), 2 = whenever the shape allows,
+        3 = 1 + the fused tail of a step (opt-in: slower); -> previous mode (no argument: query).  Process-wide
+        (include/qbm_hip.h: qbm_rbm_fused_chain_mode)."""
         return int(self.lib.qbm_rbm_fused_chain_mode(int(mode)))
 
-    _STATUS_TEXT = {1: "a barrier between phases timed out", 2: "the workgroups of a row block were not placed on one XCD"}
+    _STATUS_TEXT = {1: "a barrier between phases timed out", 2: "the workgroups of a row block were not placed on one XCD",
+                    3: "the barrier between the last hidden phase and the gradient timed out",
+                    4: "the workgroups of a column group were not placed on one XCD"}
 
     def check_chain_status(self, ws=None):
         """Look at the status word of the fused chain kernel (include/qbm_hip.h: qbm_rbm_cd_workspace.sync).  Synchronises;
         train_rbm calls it at the end of every epoch, cd_step every kPendingMax steps.
         ws given (a caller-owned workspace): raise if a launch on it gave up.
-        ws None (the workspaces cd_step keeps): a launch that gave up has changed NOTHING -- the gradient launch behind it and
-        every later chain / gradient launch on the buffer were no-ops (FAIL-SAFE in the header) -- so the steps since then are
-        repeated here on the launch-per-phase path (same draws, same bits), the process stays on that path
+        ws None (the workspaces cd_step keeps): every launch behind one that gave up was a no-op (FAIL-SAFE in the header).
+        A one-launch chain that gave up (status 1 / 2) has changed NOTHING: the steps since then are repeated here on the
+        launch-per-phase path (same draws, same bits).  A fused tail that gave up (status 3 / 4) with the update inside may
+        have applied the update of some column groups: that step is first FINISHED from its untouched workspace
+        (qbm_rbm_cd_step_finish), then the later steps are repeated.  The process stays on the launch-per-phase path
         (qbm_rbm_fused_chain_mode(0)) and a RuntimeWarning says so."""
         if ws is not None:
             if len(ws) > 5 and ws[5] is not None:
                 st = int(ws[5][512].item())
                 if st != 0:
                     raise _lib.QbmHipError(
-                        f"fused Gibbs chain kernel gave up (status {st}: {self._STATUS_TEXT.get(st, 'unknown')}): the step did not "
-                        "reach the parameters; re-zero the workspace's sync buffer and repeat it with QBM_FUSED_CHAIN=0 "
-                        "(one launch per phase)")
+                        f"fused Gibbs chain kernel gave up (status {st}: {self._STATUS_TEXT.get(st, 'unknown')}): " +
+                        ("the step did not reach the parameters; re-zero the workspace's sync buffer and repeat it with "
+                         "QBM_FUSED_CHAIN=0 (one launch per phase)" if st in (1, 2) else
+                         "with fuse_update part of the step's update may have been applied: complete it with "
+                         "qbm_rbm_cd_step_finish (word 515 = round) before re-zeroing the sync buffer; later steps did nothing"))
             return
         pending, self._pending = self._pending, []
         if self._sync is None or not pending:
             return
-        st, off_lo = (int(x) & 0xFFFFFFFF for x in self._sync[512:514].tolist())   # one synchronising copy
+        st, off_lo, _, rnd = (int(x) & 0xFFFFFFFF for x in self._sync[512:516].tolist())   # one synchronising copy
         if self.status_agree is not None:   # data-parallel group: every rank repeats from the first step ANY rank lost
             st, off_lo = self.status_agree(st, off_lo)
         if st == 0:
             return
         import warnings
 
-        first = next((i for i, (o, _) in enumerate(pending) if o == (off_lo & 0xFFFFFFFF)), None)
+        first = next((i for i, (o, _, _) in enumerate(pending) if o == (off_lo & 0xFFFFFFFF)), None)
         if first is None:
             raise _lib.QbmHipError(
                 f"fused Gibbs chain kernel gave up (status {st}: {self._STATUS_TEXT.get(st, 'unknown')}) in a step this object "
                 "no longer holds: the steps since then did not reach the parameters; set QBM_FUSED_CHAIN=0 and repeat them")
         self.fused_chain_mode(0)
+        finish = pending[first][2] if st in (3, 4) else None
+        if finish is not None:   # the fused tail with the update inside: complete that step from its workspace, as it left it
+            finish(rnd)
+            first += 1
         self._sync.zero_()
         warnings.warn(f"fused Gibbs chain kernel gave up (status {st}: {self._STATUS_TEXT.get(st, 'unknown')}); nothing was "
-                      f"written since. Repeating {len(pending) - first} step(s) with one launch per phase (same bits) and "
+                      f"written since. " + ("Finished that step from its workspace; r" if finish is not None else "R") +
+                      f"epeating {len(pending) - first} step(s) with one launch per phase (same bits) and "
                       "staying on that path (qbm_rbm_fused_chain_mode(0)).", RuntimeWarning)
-        for _, fn in pending[first:]:
+        for _, fn, _ in pending[first:]:
             fn()
 
     def update(self, P: ParamSet, G: GradSet, lr, factor, batch_size, sparse, with_gb=True, count_dev=None, guard_chain=False):

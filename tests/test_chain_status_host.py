@@ -13,7 +13,7 @@ from qbm_image_classification_amd._lib import QBM_U8, QbmHipError
 
 class _StubLib:
     def __init__(self):
-        self.mode, self.cd_calls = 1, 0
+        self.mode, self.cd_calls, self.finished = 1, 0, []
 
     def qbm_rbm_fused_chain_mode(self, m):
         prev = self.mode
@@ -23,6 +23,10 @@ class _StubLib:
 
     def qbm_rbm_cd_step(self, *a):
         self.cd_calls += 1
+        return 0
+
+    def qbm_rbm_cd_step_finish(self, *a):
+        self.finished.append((a[8].value if hasattr(a[8], "value") else a[8], a[-2]))   # (draw offset, round)
         return 0
 
 
@@ -55,7 +59,7 @@ def test_status_survives_workspace_rekeying_and_steps_are_replayed(ops):
         _step(ops, P, G, B, 7 * i, log)
     assert len(ops._cd_wss) == 2
     assert all(w[5] is ops._sync for w in ops._cd_wss.values())          # one state buffer for every cached workspace
-    assert [o for o, _ in ops._pending] == [0, 7, 14, 21]
+    assert [o for o, _, _ in ops._pending] == [0, 7, 14, 21]
     ops._sync[512], ops._sync[513] = 2, 14                               # "the third step's chain gave up (XCD placement)"
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter("always")
@@ -94,3 +98,20 @@ def test_group_agreement_hook_decides(ops):
         warnings.simplefilter("ignore")
         ops.check_chain_status()
     assert log == [0, 3, 6, 3, 6] and QBM_U8 == 1
+
+
+def test_fused_tail_that_gave_up_is_finished_then_the_later_steps_are_repeated(ops):
+    """Status 3 (the fused tail of a step -- last hidden phase + gradient + update in one launch -- gave up): part of that
+    step's update may have been applied, so it is FINISHED from its workspace (qbm_rbm_cd_step_finish with the recorded
+    round), never repeated; the steps behind it, which did nothing, are repeated."""
+    P, G, log = _P(), rbm_ops.GradSet(32, 16, 2, "cpu"), []
+    for i in range(4):
+        _step(ops, P, G, 64, 7 * i, log)
+    ops._sync[512], ops._sync[513], ops._sync[515] = 3, 7, 41            # "the second step's fused tail: barrier timed out in round 41"
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        ops.check_chain_status()
+    assert ops.lib.finished == [(7, 41)]
+    assert log == [0, 7, 14, 21, 14, 21]                                 # step 2 finished, steps 3 and 4 again
+    assert ops.lib.mode == 0 and not ops._sync.any() and ops._pending == []
+    assert any("Finished that step" in str(w.message) and "epeating 2 step" in str(w.message) for w in rec)

@@ -157,3 +157,66 @@ def test_short_last_minibatch_keeps_the_status_buffer(ops):
     assert len(ops._pending) == 3
     ops.check_chain_status()
     assert ops._pending == [] and int(ops._sync[512]) == 0
+
+
+@pytest.mark.parametrize("kind,fuse", [(2, True), (1, True), (2, False)])
+def test_fused_tail_that_gives_up_is_finished_and_later_steps_repeated(oracle, kind, fuse):
+    """The fused tail of a CD-1 step (k_hgrad) with ONE workgroup made to misbehave in the second of four steps
+    (qbm_test_hgrad_fault) -- kind 2: it gives up in front of the barrier (its partners complete their share of the update:
+    the step is PARTLY applied); kind 1: it leaves at its start as if it had not been resident in time (its partners' bounded
+    barrier really times out: none of that column group's items run, and its own hidden phase is missing).  Steps 3 and 4 must
+    change nothing; check_chain_status then finishes step 2 from its workspace (with the update inside the launch) or repeats
+    it (gradients materialised: the parameters were never touched) and repeats steps 3 and 4: parameters equal the oracle's
+    after four undisturbed steps, bit for bit."""
+    from qbm_image_classification_amd.rbm_ops import GradSet, HipRbmOps
+
+    ops = HipRbmOps("cuda:0")
+    prev = ops.fused_chain_mode(3)      # the fused tail is an opt-in
+    try:
+        V, H, C, B, k = 784, 512, 10, 256, 1
+        W, b, d, U, c = synth_params(V, H, C, 177)
+        P = P_of(ops, W, b, d, U, c)
+        G = GradSet(V, H, C, ops.device)
+        seed, lr, sparse = 5, 0.05, 0.001
+        data = [synth_inputs(B, V, H, C, 180 + s) for s in range(4)]
+
+        def step(s):
+            v8, y = dev(ops, data[s][0].astype(np.uint8)), dev(ops, data[s][4])
+            off, row0 = 4 * s, B * s
+
+            def run():
+                ops.cd_step(P, G, v8, y, k, seed, off, row0, None, None, fuse, lr, 1.0, float(B), sparse, replay=run)
+                if not fuse:
+                    ops.update(P, G, lr, 1.0, float(B), sparse, guard_chain=True)
+            run()
+
+        step(0)
+        _oracle_step(oracle, W, b, d, U, c, data[0][0], data[0][4], k, seed, 0, 0, lr, B, sparse)
+        assert_bitwise(P.W, W, "W after the first (healthy) step")
+        ops.lib.qbm_test_hgrad_fault(77, kind)                                # workgroup 77 of the NEXT fused tail
+        step(1)
+        torch.cuda.synchronize()
+        st = ops._sync[512:516].tolist()
+        assert st[0] == 3 and st[1] == 4 and st[3] == 2, st                   # barrier, draw offset of step 2, round 2
+        snap = [t.clone() for t in (P.W, P.b, P.d, P.U, P.c)]
+        if fuse and kind == 2:
+            assert not torch.equal(P.W, dev(ops, W)), "the healthy column groups have applied their update"
+        if not fuse:
+            assert_bitwise(P.W, W, "W untouched (gradients materialised, guarded update)")
+        step(2)
+        step(3)
+        torch.cuda.synchronize()
+        for a, bb in zip(snap, (P.W, P.b, P.d, P.U, P.c)):
+            assert torch.equal(a, bb), "steps behind a fused tail that gave up must not store anything"
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            ops.check_chain_status()
+        msg = [str(w.message) for w in rec]
+        assert any("gave up" in m and ("Finished that step" in m) == fuse for m in msg), msg
+        assert ops.fused_chain_mode() == 0 and not ops._sync.any() and ops._pending == []
+        for s in (1, 2, 3):
+            _oracle_step(oracle, W, b, d, U, c, data[s][0], data[s][4], k, seed, 4 * s, B * s, lr, B, sparse)
+        for got, want, nm in ((P.W, W, "W"), (P.b, b, "b"), (P.d, d, "d"), (P.U, U, "U"), (P.c, c, "c")):
+            assert_bitwise(got, want, f"{nm} after finishing / repeating")
+    finally:
+        ops.fused_chain_mode(prev)

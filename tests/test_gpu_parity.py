@@ -765,3 +765,76 @@ def test_sample_q_on_reference_conv_qbm_qubo(oracle):
             assert E.mean() <= Eo.min() + 0.005 * abs(Eo.min()), (name, img, E.mean(), Eo.min())
             assert link >= 0.99 and link_o >= 0.99, (link, link_o)
             assert abs(amo - amo_o) <= 0.02, (amo, amo_o)
+
+
+@pytest.mark.parametrize("V,H,C,B,k,pcd", [(784, 512, 10, 256, 1, False), (784, 512, 10, 256, 1, True), (784, 128, 2, 128, 1, False),
+                                           (784, 128, 2, 512, 1, False), (64, 128, 12, 96, 1, False), (784, 512, 10, 48, 1, True),
+                                           (784, 256, 4, 320, 1, False)])
+def test_fused_tail_equals_oracle_and_launch_per_phase(ops, oracle, V, H, C, B, k, pcd):
+    """The fused tail of a CD step (k_hgrad: last hidden phase, XCD-local barrier among the workgroups of a column group,
+    two-phase gradient over 128-row W strips, update -- ONE launch) against the oracle and against the launch-per-phase
+    path, bit for bit: three steps in a row on the same workspace with the parameters (and the persistent chains) carried
+    over (the barrier rounds carry over from launch to launch), update fused and gradients materialised, with the training
+    loop's monitor riding along; the status word stays 0.  Shapes: the benchmark's, PCD-1, config #2's, more row strips than
+    8 (B = 512 at H = 128: 16 workgroups per group, two panels per K chain), a ragged number of W strips and 12 classes, a
+    partial last row strip, H = 256 (B > 256 is not a shape the fused tail takes: those cases run the launch-per-phase tail in
+    both modes).  The fused tail is an opt-in (mode 3: it is slower than the launch-per-phase tail)."""
+    from qbm_image_classification_amd.rbm_ops import GradSet
+
+    seed, lr, sparse = 23, 0.05, 0.0005
+    prev = ops.fused_chain_mode(-1)
+    results = {}
+    try:
+        for mode in (3, 0):
+            ops.fused_chain_mode(mode)
+            for fuse in (True, False):
+                W, b, d, U, c = synth_params(V, H, C, 1200 + V + H)
+                P = P_of(ops, W, b, d, U, c)
+                G = GradSet(V, H, C, ops.device)
+                ws = ops.cd_workspace(P, B)
+                cws = None
+                sums = torch.zeros(2, dtype=torch.float64, device=ops.device)
+                v_init, _, _, _, y_init = synth_inputs(B, V, H, C, 70)
+                cv_o, cy_o = (v_init.copy(), y_init.copy()) if pcd else (None, None)
+                cv, cy = (dev(ops, v_init.astype(np.uint8)), dev(ops, y_init)) if pcd else (None, None)
+                for step in range(3):
+                    v_bin, _, _, labels, y1h = synth_inputs(B, V, H, C, 71 + step)
+                    off, row0 = 4 * step, B * step
+                    out = ops.cd_step(P, G, dev(ops, v_bin.astype(np.uint8)), dev(ops, y1h), k, seed, off, row0, cv, cy, fuse, lr, 1.0,
+                                      float(B), sparse, ws)
+                    if not fuse:
+                        ops.update(P, G, lr, 1.0, float(B), sparse)
+                    ph0, vk, yk, phk = oracle.rbm_cd_chain(v_bin, y1h, W, b, d, U, c, k, seed, off, row0, cv_o, cy_o)
+                    g = oracle.rbm_two_phase_grad(v_bin, y1h, ph0, vk, yk, phk)
+                    tag = f"mode {mode}, fuse {fuse}, step {step}"
+                    assert_bitwise(out[4], phk, f"p(h_k) [{tag}]")
+                    if not fuse:
+                        assert_bitwise(G.gW, g[0], f"gW [{tag}]")
+                    for got, want, nm in ((G.gb, g[1], "gb"), (G.gd, g[2], "gd"), (G.gU, g[3], "gU"), (G.gc, g[4], "gc")):
+                        assert_bitwise(got, want, f"{nm} [{tag}]")
+                    oracle.rbm_update(W, b, d, U, c, *g, lr, 1.0, float(B), sparse)
+                    for got, want, nm in ((P.W, W, "W"), (P.b, b, "b"), (P.d, d, "d"), (P.U, U, "U"), (P.c, c, "c")):
+                        assert_bitwise(got, want, f"{nm} [{tag}]")
+                assert int(ws[5][512].item()) == 0
+                results[(mode, fuse)] = [t.clone() for t in (P.W, P.b, P.d, P.U, P.c)]
+        for fuse in (True, False):
+            for x, y in zip(results[(3, fuse)], results[(0, fuse)]):
+                assert torch.equal(x, y)
+        # the monitor riding in the step: loss sums and parameters equal with and without the fused tail
+        mon = {}
+        for mode in (3, 0):
+            ops.fused_chain_mode(mode)
+            W, b, d, U, c = synth_params(V, H, C, 1300 + V + H)
+            P = P_of(ops, W, b, d, U, c)
+            G = GradSet(V, H, C, ops.device)
+            sums = torch.tensor([1.5, 0.125], dtype=torch.float64, device=ops.device)
+            for step in range(2):
+                v_bin, _, _, labels, y1h = synth_inputs(B, V, H, C, 75 + step)
+                ops.cd_step(P, G, dev(ops, v_bin.astype(np.uint8)), dev(ops, y1h), k, seed, 4 * step, 0, None, None, True, lr, 1.0, float(B),
+                            sparse, monitor=(dev(ops, labels.astype(np.int32)), sums))
+            ops.check_chain_status()
+            mon[mode] = (sums.tolist(), P.W.clone(), P.c.clone())
+        assert mon[3][0] == mon[0][0] and mon[3][0] != [1.5, 0.125]
+        assert torch.equal(mon[3][1], mon[0][1]) and torch.equal(mon[3][2], mon[0][2])
+    finally:
+        ops.fused_chain_mode(prev)

@@ -1,7 +1,7 @@
 # Evidence for profiles/: rocprofv3 kernel stats (bench + every other hot-path kernel), PMC passes (HBM traffic; MFMA busy),
 # the bench line, the in-kernel stamps.  Output under gpurun_out/profiles/ (copy into profiles/ afterwards).
-#   ROUND=r02 bash tools/gpu_profiles.sh
-R=${ROUND:-r02}
+#   ROUND=r03 bash tools/gpu_profiles.sh
+R=${ROUND:-r03}
 ROOT=$GRAFT_REPO_ROOT; [ -z "$ROOT" ] && ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles; mkdir -p $OUT; P=$ROOT/gpurun_out/progress.log; : > $P
 cd /tmp && export TMPDIR=/tmp
@@ -30,7 +30,7 @@ for d in glob.glob(root + "/gpurun_out/pmc_*"):
     if not os.path.isdir(d): continue
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            for short in ("k_hidden", "k_visible", "k_grad"):
+            for short in ("k_hidden", "k_visible", "k_grad", "k_hgrad"):
                 if short in r["Kernel_Name"]:
                     vals[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 traffic, mfma = {}, {}

@@ -80,6 +80,20 @@ def main():
     cws = _lib.CdWorkspace(p(ph0), p(h), p(vk), p(yk), p(phk), p(sync))
     lib.qbm_rbm_fused_chain_mode(2)     # the fused kernel also for CD-1 (default: from k = 2 on)
     kernels["k_chain"] = (lambda: lib.qbm_rbm_cd_chain(C.byref(P), p(v0), 1, p(y0), B, 1, 42, 0, 0, None, None, C.byref(cws), None), 256 * 8)
+    # the fused tail of a CD-1 step (k_hgrad, mode 3): last hidden phase + gradient + update in one launch
+    lib.qbm_rbm_cd_tail.argtypes = _lib.SIGNATURES["qbm_rbm_cd_tail"]
+    rnd = [0]
+
+    def tail():
+        rnd[0] += 1
+        lib.qbm_rbm_fused_chain_mode(3)      # an opt-in
+        try:
+            return lib.qbm_rbm_cd_tail(C.byref(P2), C.byref(G), p(v0), 1, p(y0), B, p(vk), p(yk), C.byref(cws), 1, 0.05, 1.0, float(B), 0.0, rnd[0], None)
+        finally:
+            lib.qbm_rbm_fused_chain_mode(2)
+    keep = [b.clone(), d.clone(), U.clone(), c.clone()]
+    P2 = _lib.RbmParams(p(Wsc), *(p(x) for x in keep), V, H, NC)
+    kernels["k_hgrad"] = (tail, 256 * 8)
     for f, _ in kernels.values():    # warm: code objects loaded, caches in their steady state
         for _ in range(3):
             assert f() == 0
@@ -100,6 +114,13 @@ def main():
                       (7, 8, "visible phase + class rows"), (8, 9, "barrier 2"), (9, 13, "hidden phase 1"),
                       (11, 0, "  last hidden phase: to strip_mma entry"), (0, 1, "  requests issued"), (1, 2, "  first quad landed"),
                       (2, 3, "  MFMA loop"), (3, 4, "  combine"), (4, 12, "  epilogue"), (5, 13, "WAVE LIFETIME")]
+    # fused tail: 5 entry, 6 / 7 before / after the barrier of the column group (the hidden phase's own slots are re-used
+    # below), 8..12 the contraction of phase 0 of the workgroup's W item (its requests went out under the hidden phase),
+    # 0..4 that of phase 1, 13 exit
+    seq["k_hgrad"] = [(5, 6, "hidden phase (+ requests of the gradient's operands)"), (6, 7, "barrier (incl. waiting for the slowest workgroup)"),
+                      (7, 8, "to the contraction of phase 0 (group 0: requests of p(h_k))"), (8, 10, "  wait for the operands"), (10, 11, "  MFMA loop"),
+                      (11, 12, "  combine"), (12, 0, "to the contraction of phase 1"), (0, 2, "  wait for the operands"), (2, 3, "  MFMA loop"),
+                      (3, 4, "  combine"), (4, 13, "epilogue + other items"), (7, 13, "GRADIENT PART"), (5, 13, "WAVE LIFETIME")]
     for name, (f, _) in kernels.items():     # back-to-back launch time of the stamped build (stamps cost a few %)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -118,7 +139,7 @@ def main():
             lib.qbm_diag_read_stamps(buf.ctypes.data_as(C.c_void_p), n_waves)
             res.append(buf)
         st = res[-1].astype(np.int64)
-        ok = ((st[:, 10] != 0) & (st[:, 12] != 0) & (st[:, 11] != 0)) if name != "k_chain" else (st[:, 13] != 0)     # workgroups that ran to the end
+        ok = ((st[:, 10] != 0) & (st[:, 12] != 0) & (st[:, 11] != 0)) if name not in ("k_chain", "k_hgrad") else (st[:, 13] != 0)     # workgroups that ran to the end
         st = st[ok]
         print(f"== {name}: {ok.sum()} stamped waves (s_memtime is per XCD: only differences inside one wave are meaningful)")
         for a, bb, what in seq[name]:
