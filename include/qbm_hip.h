@@ -182,9 +182,10 @@ typedef struct {
                      * buffer per stream of concurrent work; workspaces of different shapes on one stream may share it. */
     /* The training loop's monitor, qbm_rbm_cd_step only (all five set, or mon_labels NULL = off): the step also evaluates
      * p(y|x0) of its minibatch under the parameters BEFORE its update -- what discriminative_training reports
-     * (src/ClassificationRBM.py:108, :142) -- from v0.W + d, which the positive-phase launch stores on the way (one more
-     * kernel, no further contraction), and books the minibatch means of the two loss terms into mon_loss_acc
-     * (qbm_rbm_disc_workspace.rowloss / loss_acc: same definitions). */
+     * (src/ClassificationRBM.py:108, :142) -- from v0.W + d, which the positive-phase launch stores on the way (no further
+     * contraction; the rows' free energies ride as extra workgroups in the sample_visible launch for B <= 512, a launch of
+     * their own otherwise and behind the one-launch chain), and books the minibatch means of the two loss terms into
+     * mon_loss_acc (qbm_rbm_disc_workspace.rowloss / loss_acc: same definitions) inside the gradient launch. */
     const int32_t* mon_labels; /* [B] */
     float* mon_pre;            /* [B,H] */
     float* mon_p;              /* [B,C] p(y|x0) */

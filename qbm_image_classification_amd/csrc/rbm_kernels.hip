@@ -405,6 +405,13 @@ __global__ __launch_bounds__(256) void k_class(const void* __restrict__ h, const
     class_row<TH, CM>(h, U, cb, p_out, y_out, (int)blockIdx.x, H, C, seed, offset, row0, e_s);
 }
 
+// (defined with k_free_energy below; the training loop's monitor rides in the k_visible launch as aux workgroups)
+template <int CM>
+__device__ __forceinline__ void free_energy_row(const float* __restrict__ pre, const float* __restrict__ U,
+                                                const float* __restrict__ cb, float* __restrict__ negF, float* __restrict__ p_out,
+                                                int i, int H, int C, const int* __restrict__ labels, float* __restrict__ diff,
+                                                float* __restrict__ rowloss, int tid, int nw, float* __restrict__ sm);
+
 // ---------------------------------------------------------------------------------------------
 // A-2  sample_visible  (src/ClassificationRBM.py:49-52):  p = sigma(h.W^T + b);  v = (p > u)
 // W is read as stored ([V,H], H contiguous): it is the K-contiguous B operand.
@@ -429,6 +436,9 @@ struct VisibleArgs {
     int C; uint64_t offset_y;
     int n_aux;  // aux workgroups come first in the grid
     const uint32_t* status;   // as HiddenArgs::status
+    // the training loop's monitor riding along (qbm_rbm_cd_workspace.mon_*): n_fe = B more aux workgroups behind the class
+    // rows, one row each: -F, p(y|x0) and the row's two loss terms from x0.W + d (stored by the launch in front)
+    int n_fe; const float* fe_pre; const int* fe_labels; float* fe_p; float* fe_rowloss;
     uint32_t* hg_round;       // non-null: the fused tail of the step (k_hgrad) is the next launch: this one advances the word
                               // that launch takes its barrier round from (one writer, a kernel boundary in front of the readers:
                               // the same number in every workgroup whatever shapes earlier launches on the buffer had)
@@ -507,7 +517,7 @@ __global__ __launch_bounds__(64 * V_NQ) void k_visible(VisibleArgs a)
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int nMs = (a.B + 16 * V_MT - 1) / (16 * V_MT), nNs = (a.V + 16 * V_NT - 1) / (16 * V_NT);
     {   // aux workgroups behind a fused launch that gave up: nothing to do (the strips test the word in front of their stores)
-        const bool is_aux = a.n_aux == a.B ? (int)blockIdx.x < a.n_aux : (int)blockIdx.x >= nMs * nNs;
+        const bool is_aux = a.n_aux == a.B ? (int)blockIdx.x < a.n_aux + a.n_fe : (int)blockIdx.x >= nMs * nNs;
         if (a.n_aux > 0 && is_aux && a.status && *a.status != 0u) return;
     }
     if (a.hg_round && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && *a.status == 0u) *a.hg_round = *a.hg_round + 1u;
@@ -518,6 +528,13 @@ __global__ __launch_bounds__(64 * V_NQ) void k_visible(VisibleArgs a)
             if (threadIdx.x >= 256) return;
             class_row<TA, CM>(a.h, a.U, a.cb, a.py, a.ys, (int)blockIdx.x, a.H, a.C, a.seed, a.offset_y, a.row0,
                               reinterpret_cast<float*>(lds));
+            return;
+        }
+        if ((int)blockIdx.x < a.n_aux + a.n_fe) {   // the monitor: one row per workgroup, its classes dealt to the 8 wavefronts (in
+                                                    // front of the strips: behind them -- the ragged end of the launch -- they
+                                                    // start late and the launch ends 4.8 us later; measured)
+            free_energy_row<CM>(a.fe_pre, a.U, a.cb, nullptr, a.fe_p, (int)blockIdx.x - a.n_aux, a.H, a.C, a.fe_labels, nullptr,
+                                a.fe_rowloss, (int)threadIdx.x, V_NQ, reinterpret_cast<float*>(lds));
             return;
         }
     } else if ((int)blockIdx.x >= nMs * nNs) {
@@ -532,7 +549,7 @@ __global__ __launch_bounds__(64 * V_NQ) void k_visible(VisibleArgs a)
     asm volatile("" ::"s"(a.h), "s"(a.W), "s"(a.b), "s"(a.p), "s"(a.s), "s"(a.s8), "s"(a.B), "s"(a.V), "s"(a.H), "s"(a.KP),
                  "s"(a.seed), "s"(a.offset), "s"(a.row0));   // all arguments in one scalar-cache round trip (see k_hidden)
     int ms, ns;
-    strip_coords(nMs, nNs, ms, ns, a.n_aux == a.B ? a.n_aux : 0);
+    strip_coords(nMs, nNs, ms, ns, a.n_aux == a.B ? a.n_aux + a.n_fe : 0);
     visible_body<TA, FAST, V_MT, V_NT>(a, ms, ns, lds);
 }
 
@@ -709,7 +726,7 @@ __global__ __launch_bounds__(512) void k_chain(ChainArgs a)
         } else {
             if (j < nNv) {
                 const VisibleArgs va{a.h, a.W, a.b, nullptr, nullptr, vout, a.B, a.V, a.H, a.KPv, a.seed, off - 2, a.row0, a.vecO,
-                                     a.U, a.c, nullptr, yout, a.C, off - 1, 0, nullptr, nullptr};
+                                     a.U, a.c, nullptr, yout, a.C, off - 1, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
                 visible_body<uint8_t, true, 2, 2, kSc1>(va, g, j, lds + a.ldsT);
             }
             // class conditional of the block's 32 rows, one row per wavefront, on the workgroups that have no strip -- or,
@@ -739,25 +756,26 @@ __global__ __launch_bounds__(512) void k_chain(ChainArgs a)
 // -log(p_label + 1e-8) (:188-190).
 // All loads of a stage are issued before its arithmetic (a lane's 8 columns of a 512-unit row: a dependent L2 round trip
 // per column would otherwise be most of the kernel).
+// One row by a team of NW wavefronts (tid = 0 .. 64 NW - 1; every thread of the team calls it: workgroup barriers inside):
+// wavefront w takes the classes w, w + NW, ... (k_free_energy: NW = C, one class each; as aux workgroups of k_visible:
+// NW = 8).  sm: (2 + CM) (CM + 1) floats of LDS.
 template <int CM>
-__global__ __launch_bounds__(64 * CM) void k_free_energy(const float* __restrict__ pre, const float* __restrict__ U,
-                                                         const float* __restrict__ cb, float* __restrict__ negF,
-                                                         float* __restrict__ p_out, int B, int H, int C,
-                                                         const int* __restrict__ labels, float* __restrict__ diff,
-                                                         float* __restrict__ rowloss, const uint32_t* __restrict__ status)
+__device__ __forceinline__ void free_energy_row(const float* __restrict__ pre, const float* __restrict__ U,
+                                                const float* __restrict__ cb, float* __restrict__ negF, float* __restrict__ p_out,
+                                                int i, int H, int C, const int* __restrict__ labels, float* __restrict__ diff,
+                                                float* __restrict__ rowloss, int tid, int nw, float* __restrict__ sm)
 {
-    if (status && *status != 0u) return;   // (the CD step's monitor behind a fused launch that gave up: HiddenArgs::status)
-    __shared__ float nf_s[CM + 1], p_s[CM + 1];
-    __shared__ float e_s[CM * CM];
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = class
-    const int i = blockIdx.x;
+    float* nf_s = sm;
+    float* p_s = sm + (CM + 1);
+    float* e_s = sm + 2 * (CM + 1);
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lab = labels ? labels[i] : 0;
-    {
+    for (int cls = w; cls < C; cls += nw) {
         float nf = 0.f;
-        const float cbv = cb[w];
+        const float cbv = cb[cls];
         const float* prow = pre + (long)i * H;
-        const float* urow = U + (long)w * H;
+        const float* urow = U + (long)cls * H;
         for (int jb = 0; jb < H; jb += 8 * kWave) {   // the lane chains j = lane, lane + 64, ... ascending ([T])
             float pv[8], uv[8];
 #pragma unroll
@@ -773,16 +791,16 @@ __global__ __launch_bounds__(64 * CM) void k_free_energy(const float* __restrict
             }
         }
         const float v = cbv + wave_butterfly_sum(nf);
-        if (lane == 0) nf_s[w] = v;
+        if (lane == 0) nf_s[cls] = v;
     }
     __syncthreads();
-    {
-        const int c = threadIdx.x / CM, dd = threadIdx.x % CM;
+    for (int t = tid; t < CM * CM; t += 64 * nw) {
+        const int c = t / CM, dd = t % CM;
         if (c < C && dd < C) e_s[c * CM + dd] = det_expf((-1.0f * nf_s[c]) + nf_s[dd]);
     }
     __syncthreads();
-    if (threadIdx.x < C) {
-        const int c = threadIdx.x;
+    if (tid < C) {
+        const int c = tid;
         float s = 0.f;
         for (int dd = 0; dd < C; ++dd) s = s + e_s[c * CM + dd];
         const float pc = 1.0f / s;
@@ -792,7 +810,7 @@ __global__ __launch_bounds__(64 * CM) void k_free_energy(const float* __restrict
     }
     if (!diff && !rowloss) return;
     __syncthreads();
-    if (threadIdx.x == 0 && rowloss) {
+    if (tid == 0 && rowloss) {
         float se = 0.f;
 #pragma unroll
         for (int c = 0; c < CM; ++c)
@@ -802,7 +820,7 @@ __global__ __launch_bounds__(64 * CM) void k_free_energy(const float* __restrict
         rowloss[2 * (long)i + 1] = -det_logf(py + 1e-8f);
     }
     if (!diff) return;
-    for (int j = threadIdx.x; j < H; j += blockDim.x) {
+    for (int j = tid; j < H; j += 64 * nw) {
         const float pr = pre[(long)i * H + j];
         float uv[CM];
 #pragma unroll
@@ -818,6 +836,18 @@ __global__ __launch_bounds__(64 * CM) void k_free_energy(const float* __restrict
         }
         diff[(long)i * H + j] = ps - ng;
     }
+}
+
+template <int CM>
+__global__ __launch_bounds__(64 * CM) void k_free_energy(const float* __restrict__ pre, const float* __restrict__ U,
+                                                         const float* __restrict__ cb, float* __restrict__ negF,
+                                                         float* __restrict__ p_out, int B, int H, int C,
+                                                         const int* __restrict__ labels, float* __restrict__ diff,
+                                                         float* __restrict__ rowloss, const uint32_t* __restrict__ status)
+{
+    if (status && *status != 0u) return;   // (the CD step's monitor behind a fused launch that gave up: HiddenArgs::status)
+    __shared__ float sm[(2 + CM) * (CM + 1)];
+    free_energy_row<CM>(pre, U, cb, negF, p_out, (int)blockIdx.x, H, C, labels, diff, rowloss, (int)threadIdx.x, (int)(blockDim.x >> 6), sm);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1720,7 +1750,7 @@ int launch_hidden(const qbm_rbm_params* P, const void* v, int v_dtype, const flo
 template <class TA>
 int launch_visible_t(const qbm_rbm_params* P, const void* h, int B, float* p_v, float* v_s, uint8_t* v_s8, float* p_y,
                      float* y1hot, uint64_t seed, uint64_t offset_v, uint64_t offset_y, uint32_t row0, hipStream_t st,
-                     const uint32_t* status, uint32_t* hg_round)
+                     const uint32_t* status, uint32_t* hg_round, const qbm_rbm_cd_workspace* mon)
 {
     constexpr int ASZ = (int)sizeof(TA), MT = V_MT, NT = V_NT, NQ = V_NQ;
     const bool with_class = p_y || y1hot;
@@ -1729,11 +1759,15 @@ int launch_visible_t(const qbm_rbm_params* P, const void* h, int B, float* p_v, 
                   // pairs of visible units: 8-byte accesses to p / v_f32 / b, 2-byte accesses to v_u8
                   (P->V % 2 == 0) && (!p_v || aligned8(p_v)) && (!v_s || aligned8(v_s)) && (!v_s8 || aligned2(v_s8)) &&
                       aligned8(P->b),
-                  P->U, P->c, p_y, y1hot, P->C, offset_y, with_class ? (B <= 512 ? B : (B + NQ - 1) / NQ) : 0, status, status ? hg_round : nullptr};
+                  P->U, P->c, p_y, y1hot, P->C, offset_y, with_class ? (B <= 512 ? B : (B + NQ - 1) / NQ) : 0, status, 0, nullptr, nullptr, nullptr, nullptr,
+                  status ? hg_round : nullptr};
+    if (mon && a.n_aux == B) {   // (visible_takes_monitor: the caller has asked)
+        a.n_fe = B; a.fe_pre = mon->mon_pre; a.fe_labels = mon->mon_labels; a.fe_p = mon->mon_p; a.fe_rowloss = mon->mon_rowloss;
+    }
     const bool fast = (P->H % 16 == 0) && aligned16(h) && aligned16(P->W) && small2g((long)B * P->H, ASZ) &&
                       small2g((long)P->V * P->H, 4);
-    const int grid = nM * nN + a.n_aux;
-    const size_t lds = strip_lds_bytes<MT, NT, ASZ, NQ>(a.KP);
+    const int grid = nM * nN + a.n_aux + a.n_fe;
+    const size_t lds = strip_lds_bytes<MT, NT, ASZ, NQ>(a.KP);   // (>= the aux workgroups' few hundred bytes)
 #define QBM_LAUNCH(F, CM)                                                                       \
     {                                                                                           \
         if (int rc = set_lds(k_visible<TA, F, CM>, lds)) return rc;                             \
@@ -1750,12 +1784,17 @@ int launch_visible_t(const qbm_rbm_params* P, const void* h, int B, float* p_v, 
 
 int launch_visible(const qbm_rbm_params* P, const void* h, int h_dtype, int B, float* p_v, float* v_s, uint8_t* v_s8,
                    float* p_y, float* y1hot, uint64_t seed, uint64_t offset_v, uint64_t offset_y, uint32_t row0,
-                   hipStream_t st, const uint32_t* status = nullptr, uint32_t* hg_round = nullptr)
+                   hipStream_t st, const uint32_t* status = nullptr, uint32_t* hg_round = nullptr,
+                   const qbm_rbm_cd_workspace* mon = nullptr)
 {
     return h_dtype == QBM_U8
-               ? launch_visible_t<uint8_t>(P, h, B, p_v, v_s, v_s8, p_y, y1hot, seed, offset_v, offset_y, row0, st, status, hg_round)
-               : launch_visible_t<float>(P, h, B, p_v, v_s, v_s8, p_y, y1hot, seed, offset_v, offset_y, row0, st, status, hg_round);
+               ? launch_visible_t<uint8_t>(P, h, B, p_v, v_s, v_s8, p_y, y1hot, seed, offset_v, offset_y, row0, st, status, hg_round, mon)
+               : launch_visible_t<float>(P, h, B, p_v, v_s, v_s8, p_y, y1hot, seed, offset_v, offset_y, row0, st, status, hg_round, mon);
 }
+
+// Does the k_visible launch of a CD step carry the training loop's monitor (one aux workgroup per row)?  Only where the
+// class conditional rides as one workgroup per row too (B <= 512) and the first Gibbs iteration is a launch of its own.
+inline bool visible_takes_monitor(int B) { return B <= 512; }
 
 // what the gradient launch of the discriminative step carries besides the strips (kind D workgroups, one phase)
 struct DiscExtras {
@@ -2155,7 +2194,7 @@ int qbm_f32_to_u8(const float* x, uint8_t* y, long n, void* stream)
 static int cd_chain_impl(const qbm_rbm_params* P, const void* v0, int v0_dtype, const float* y0, int B, int k, uint64_t seed,
                          uint64_t offset, uint32_t row0, uint8_t* chain_v, float* chain_y, const qbm_rbm_cd_workspace* ws,
                          void* stream, bool* fused, float* mon_pre = nullptr, bool defer_last = false,
-                         const uint32_t* hg_status = nullptr)
+                         const uint32_t* hg_status = nullptr, bool mon_in_visible = false)
 {
     *fused = false;
     if (int rc = check_params(P)) return rc;
@@ -2187,7 +2226,7 @@ static int cd_chain_impl(const qbm_rbm_params* P, const void* v0, int v0_dtype, 
         float* y_out = (chain_v && t == k) ? chain_y : ws->yk;
         // v_t and y_t both depend on h_{t-1} only: one launch (class conditional as aux workgroups)
         if (int rc = launch_visible(P, ws->h, QBM_U8, B, nullptr, nullptr, v_out, nullptr, y_out, seed, o - 2, o - 1, row0, st, hg_status,
-                                    (t == k && defer_last) ? ws->sync + kHgRound : nullptr))
+                                    (t == k && defer_last) ? ws->sync + kHgRound : nullptr, (t == 1 && mon_in_visible) ? ws : nullptr))
             return rc;
         if (t == k && defer_last) break;
         // the hidden SAMPLE of the last iteration has no consumer (the gradient uses p(h_k)): no draw, no store
@@ -2226,12 +2265,14 @@ int qbm_rbm_cd_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void*
     const bool hg = B > 0 && batch_size > 0.f && v0 && y0 && ws && ws->ph0 && ws->phk && v1 && y1 &&
                     hgrad_eligible(P, G, v0, v0_dtype, y0, B, v1, y1, ws, fuse_update);
     const uint32_t* hg_status = hg ? ws->sync + 512 : nullptr;
+    // (the monitor's rows ride in the first k_visible launch as aux workgroups where that launch exists and B allows)
+    const bool mon_vis = mon && visible_takes_monitor(B);
     if (int rc = cd_chain_impl(P, v0, v0_dtype, y0, B, k, seed, offset, row0, chain_v, chain_y, ws, stream, &fused,
-                               mon ? ws->mon_pre : nullptr, hg, hg_status))
+                               mon ? ws->mon_pre : nullptr, hg, hg_status, mon_vis))
         return rc;
     if (B == 0) return zero_grads(P, G, (hipStream_t)stream);
     if (!(batch_size > 0.f)) return fail(QBM_ERR_ARG, "cd_step: batch_size must be positive");
-    if (mon) {
+    if (mon && (fused || !mon_vis)) {
         hipStream_t st = (hipStream_t)stream;
         // the one-launch chain does not deliver v0.W + d: one contraction of its own
         if (fused)

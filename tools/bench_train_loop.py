@@ -81,11 +81,28 @@ def rbm_lines(n_images, reps):
         raw()
         t_raw = best_of(raw, reps)
         ops.check_chain_status()
+        # ... and the same loop with the training loop's monitor riding in the step (what train_rbm asks of the C ABI): the
+        # difference to `raw` is the monitor's device cost, the difference to train_rbm is Python
+        t_mon = None
+        if method != "discriminative":
+            sums = torch.zeros(2, dtype=torch.float64, device=rbm.device)
+
+            def raw_mon():
+                ep[0] += 1
+                for i, (xb, lab, one) in enumerate(ds.batches(ep[0], True)):
+                    n = xb.shape[0]
+                    ops.cd_step(P, G, xb, one, k, 42, (3 * k + 1) * i, 0, None if cv is None else cv[:n], None if cy is None else cy[:n],
+                                True, 0.05, 1.0, float(n), 0.0, monitor=(lab, sums))
+
+            raw_mon()
+            t_mon = best_of(raw_mon, reps)
+            ops.check_chain_status()
         name = method + (f" PCD-{k}" if pcd else (f" CD-{k}" if method == "generative" else ""))
         print(json.dumps({"what": f"train_rbm {name}, 784x512 C=10 B=256, {n_images} bit-packed images from DeviceDataset, one epoch",
                           "steps": n_steps, "train_rbm_ms_per_epoch": round(t_loop * 1e3, 2), "train_rbm_us_per_step": round(t_loop / n_steps * 1e6, 2),
                           "train_rbm_images_per_s": round(n_images / t_loop, 1), "raw_step_loop_ms_per_epoch": round(t_raw * 1e3, 2),
                           "raw_us_per_step": round(t_raw / n_steps * 1e6, 2), "raw_images_per_s": round(n_images / t_raw, 1),
+                          "raw_with_monitor_us_per_step": None if t_mon is None else round(t_mon / n_steps * 1e6, 2),
                           "train_rbm_over_raw": round(t_loop / t_raw, 3)}), flush=True)
 
 
