@@ -49,28 +49,31 @@ template <int NFT>
 struct JTri {
     const float* tri;   // LDS
     int n;
-    int ci[NFT];        // S(i) - i of this lane's spins: T(i, p) = tri[ci + p] for i < p
-    int ic[NFT];        // this lane's spin indices, clamped to n - 1
+    int ci[NFT];        // BYTE offset of S(i) - i for this lane's spins: T(i, p) at tri + ci + 4 p for i < p
+    int ic[NFT];        // BYTE offset of this lane's spin indices (clamped to n - 1)
     __device__ __forceinline__ void setup(int lane)
     {
 #pragma unroll
         for (int tt = 0; tt < NFT; ++tt) {
             const int i = min(64 * tt + lane, n - 1);
-            ic[tt] = i;
-            ci[tt] = i * n - (i * (i - 1)) / 2 - i;
+            ic[tt] = 4 * i;
+            ci[tt] = 4 * (i * n - (i * (i - 1)) / 2 - i);
         }
     }
     template <int T, int NF>
     __device__ __forceinline__ void row(int p, int lane, float (&out)[NF]) const
     {
-        const int up = p * n - (p * (p - 1)) / 2 - p;   // wave-uniform: T(p, i) = tri[up + i] for i >= p
+        // wave-uniform (scalar unit): T(p, i) at tri + up + 4 i for i >= p; one vector add per tile in front of its read
+        // 4 (p n - p (p - 1) / 2 - p) = 2 p (2 n - 1 - p): three scalar instructions
+        const int up = 2 * p * (2 * n - 1 - p), p4 = 4 * p;
+        const char* base = reinterpret_cast<const char*>(tri);
 #pragma unroll
         for (int tt = 0; tt < NF; ++tt) {
             int ad;
-            if (tt < T) ad = ci[tt] + p;                 // every spin of an earlier tile is below p
+            if (tt < T) ad = ci[tt] + p4;                // every spin of an earlier tile is below p
             else if (tt > T) ad = up + ic[tt];           // every spin of a later tile is above p
-            else ad = (ic[tt] >= p) ? up + ic[tt] : ci[tt] + p;
-            out[tt] = tri[ad];
+            else ad = (ic[tt] >= p4) ? up + ic[tt] : ci[tt] + p4;
+            out[tt] = *reinterpret_cast<const float*>(base + ad);
         }
     }
 };
@@ -108,24 +111,29 @@ __device__ __forceinline__ void gibbs_chain(const float* __restrict__ lin, const
     }
     const uint32_t row = chain0 + (uint32_t)ch;   // Philox row: the GLOBAL chain index (sharding-invariant draws)
     float F[NF], thr[NF], jrow[NF];
-    bool st[NF];   // this lane's spin of tile t
+    // The states of a tile's 64 spins are ONE wave-uniform 64-bit mask (scalar registers): "which lanes want to flip" is a
+    // ballot XOR the mask, the flip one scalar XOR -- no per-lane state, no second ballot.  (The counters said what bounds
+    // this loop: vector-instruction issue, 4 cycles per instruction and wavefront, 3.75 wavefronts per SIMD; per-lane bools
+    // cost a dozen vector instructions per flip in packing and unpacking alone: profiles/r03_qubo_pmc.json.)
+    unsigned long long sm[NF];
 
     // start state s_i = (u < 0.5), draw id `offset`
 #pragma unroll
     for (int t = 0; t < NF; ++t) {
         const int i = 64 * t + lane;
-        st[t] = false;
+        bool s0 = false;
         F[t] = 0.f;
         if (i < n) {
             const f32x4 u = uniform4(seed, offset, row, (uint32_t)(i >> 2));
-            st[t] = u[i & 3] < 0.5f;
+            s0 = u[i & 3] < 0.5f;
             F[t] = lin[(long)b * n + i];
         }
+        sm[t] = __ballot(s0);
     }
     // initial fields: + J[j, :] for set spins j ascending
 #pragma unroll
     for (int t = 0; t < NF; ++t) {
-        unsigned long long m = __ballot(st[t]);
+        unsigned long long m = sm[t];
         while (m) {
             const int j = 64 * t + __builtin_ctzll(m);
             m &= m - 1;
@@ -163,23 +171,22 @@ __device__ __forceinline__ void gibbs_chain(const float* __restrict__ lin, const
             unsigned long long pending = (cnt >= 64) ? ~0ull : (cnt <= 0 ? 0ull : ((1ull << cnt) - 1ull));  // spins of this tile not yet visited
             while (pending) {
                 const bool ns = (beta * F[t]) < thr[t];
-                const unsigned long long want = __ballot(ns != st[t]) & pending;
+                const unsigned long long want = (__ballot(ns) ^ sm[t]) & pending;
                 if (want == 0ull) break;
                 const int l = __builtin_ctzll(want);              // first spin that flips; the ones before it stay
-                const bool was = (__ballot(st[t]) >> l) & 1ull;
-                const float sg = was ? -1.0f : 1.0f;
+                const float sg = ((sm[t] >> l) & 1ull) ? -1.0f : 1.0f;
                 row_of_tile<NF>(jr, t, 64 * t + l, lane, jrow);
 #pragma unroll
                 for (int tt = 0; tt < NF; ++tt) F[tt] = __builtin_fmaf(sg, jrow[tt], F[tt]);
-                if (lane == l) st[t] = !was;
-                pending = (l >= 63) ? 0ull : (pending & (~0ull << (l + 1)));
+                sm[t] ^= 1ull << l;
+                pending &= (~0ull << l) << 1;                      // the spins behind l
             }
         }
     }
 #pragma unroll
     for (int t = 0; t < NF; ++t) {
         const int i = 64 * t + lane;
-        if (i < n) states[(long)ch * n + i] = st[t] ? 1 : 0;
+        if (i < n) states[(long)ch * n + i] = (uint8_t)((sm[t] >> lane) & 1ull);
     }
 }
 

@@ -116,7 +116,8 @@ def main():
             q.train_for_one_iteration(X, Y, 0.01)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
         out.append({"what": f"Disc_QBM.train_for_one_iteration 784v/256h B=73 R=100 sweeps={sweeps} (146 QUBOs)", "ms": round(dt * 1e3, 2),
-                    "ms_per_qubo": round(dt * 1e3 / 146, 3)})
+                    "ms_per_qubo": round(dt * 1e3 / 146, 3), "chain_sweeps_per_s": round(2 * 73 * 100 * sweeps / dt, 1),
+                    "spin_updates_per_s": round(73 * 100 * sweeps * (256 + 257) / dt, 1)})
         print(json.dumps(out[-1]), flush=True)
 
 

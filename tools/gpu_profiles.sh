@@ -23,6 +23,9 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $ROOT/gpurun_out/pmc_$tag -- python3 $ROOT/bench.py --steps 200 --warmup 20 --graph 0 --no-cpu-baseline > /dev/null 2> $ROOT/gpurun_out/pmc_$tag.err
   echo "pmc $tag rc=$?" >> $P
 done
+# the QUBO Gibbs kernel (96 % of a Disc_QBM iteration): instruction mix, LDS activity and bank conflicts
+ROUND=$R bash $ROOT/tools/qubo_pmc.sh > $ROOT/gpurun_out/qubo_pmc.log 2>&1; echo "qubo pmc rc=$?" >> $P
+cp $ROOT/gpurun_out/qubo_pmc.json $OUT/${R}_qubo_pmc.json
 cd $ROOT
 python3 - <<PY
 import csv, glob, json, os, collections
@@ -60,4 +63,5 @@ timeout -k 10 300 python bench.py > $OUT/${R}_bench.json 2> gpurun_out/bench.err
 timeout -k 10 150 python bench.py --force-dp --no-cpu-baseline > $OUT/${R}_bench_forced_dp.json 2>> gpurun_out/bench.err; echo "bench dp rc=$?" >> $P
 timeout -k 10 200 python tools/bench_configs.py > $OUT/${R}_other_configs.jsonl 2> gpurun_out/configs.err; echo "configs rc=$?" >> $P
 timeout -k 10 200 python tools/qbm_pipeline.py --time > $OUT/${R}_qbm_pipeline.jsonl 2> gpurun_out/qbm_pipeline.err; echo "qbm rc=$?" >> $P
+timeout -k 10 120 python tools/qubo_bench.py > $OUT/${R}_qubo_bench.jsonl 2> gpurun_out/qubo_bench.err; echo "qubo bench rc=$?" >> $P
 cat $P; head -c 600 $OUT/${R}_bench.json

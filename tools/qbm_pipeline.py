@@ -91,7 +91,9 @@ def time_iteration(B=73, R=100, sweeps=100, hidden=256, reps=10):
         q.train_for_one_iteration(X, Y, 0.01)      # reference API: host arrays in, host scalars out (one sync per call)
     api_ms = (time.perf_counter() - t0) / reps * 1e3
     return {"what": "Disc_QBM.train_for_one_iteration", "B": B, "R": R, "sweeps": sweeps, "hidden": hidden,
-            "ms_device_resident_step": round(dev_ms, 3), "ms_reference_api_call": round(api_ms, 3)}
+            "ms_device_resident_step": round(dev_ms, 3), "ms_reference_api_call": round(api_ms, 3),
+            "chain_sweeps_per_s": round(2 * B * R * sweeps / dev_ms * 1e3, 1),
+            "spin_updates_per_s": round(B * R * sweeps * (2 * hidden + 1) / dev_ms * 1e3, 1)}
 
 
 if __name__ == "__main__":
