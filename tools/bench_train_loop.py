@@ -106,6 +106,38 @@ def rbm_lines(n_images, reps):
                           "train_rbm_over_raw": round(t_loop / t_raw, 3)}), flush=True)
 
 
+def dp_line(n_images, reps):
+    """The data-parallel code path of the PRODUCT loop on ONE rank (no multi-GPU box is available to the build: N > 1 is
+    unmeasured on hardware): ClassificationRBM(data_parallel=True).train_rbm under a 1-rank RCCL group -- per step the chain,
+    the gradient launch writing its row count, ONE all-reduce of the flat gradient buffer, and qbm_rbm_update_dev reading the
+    global row count on the device (no host round trip)."""
+    import torch.distributed as dist
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", device_id=torch.device("cuda:0"))
+    try:
+        rs = np.random.RandomState(0)
+        x = (rs.random_sample((n_images, V)) < 0.2).astype(np.uint8)
+        y = rs.randint(0, C, n_images)
+        for method in ("generative", "discriminative"):
+            ds = DeviceDataset(x, y, B, C, storage="bits", seed=1)
+            rbm = ClassificationRBM(V, H, 1, num_classes=C, learning_rate=0.05, seed=42, device="cuda:0", data_parallel=True)
+
+            def drop_in():
+                with contextlib.redirect_stdout(io.StringIO()):
+                    rbm.train_rbm(ds, epochs=1, method=method)
+
+            drop_in()
+            t = best_of(drop_in, reps)
+            print(json.dumps({"what": f"train_rbm {method}{' CD-1' if method == 'generative' else ''}, DATA-PARALLEL code path on ONE rank (1-rank RCCL "
+                                      f"group; N > 1 unmeasured on hardware), 784x512 C=10 B=256, {n_images} images, one epoch",
+                              "steps": len(ds), "train_rbm_ms_per_epoch": round(t * 1e3, 2), "train_rbm_us_per_step": round(t / len(ds) * 1e6, 2),
+                              "train_rbm_images_per_s": round(n_images / t, 1)}), flush=True)
+    finally:
+        dist.destroy_process_group()
+
+
 def qbm_lines(reps, n_batches=20, sweeps=100):
     from qbm_image_classification_amd.disc_qbm import Disc_QBM
 
@@ -146,9 +178,12 @@ if __name__ == "__main__":
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--quick", action="store_true", help="6 016 images, one repetition")
     ap.add_argument("--no-qbm", action="store_true")
+    ap.add_argument("--no-dp", action="store_true", help="skip the data-parallel code path on one rank")
     a = ap.parse_args()
     if a.quick:
         a.images, a.reps = 6016, 1
     rbm_lines(a.images, a.reps)
     if not a.no_qbm:
         qbm_lines(a.reps)
+    if not a.no_dp:
+        dp_line(a.images, a.reps)
