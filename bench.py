@@ -188,8 +188,9 @@ def main():
         torch.cuda.synchronize()
 
     # ---- roofline, part 1: per-kernel launch duration with HIP events on the launching stream.  Runs BEFORE the timed
-    # region: its ~3000 launches also bring the GPU to its steady clock state, so that a short timed region (the driver
-    # times 20 steps = 0.6 ms) measures the same state a long one does ----------------------------------------------
+    # region, on every rank: its ~3000 launches also bring the GPU to its steady clock state, so that a short timed region
+    # (the driver times 20 steps = 0.6 ms) measures the same state a long one does; the JSON line says how many launches
+    # that was (config.pre_timed_kernel_launches) -------------------------------------------------------------------
     def time_kernel(fn, reps=1000, per_graph=50, prologue=None):
         """average duration of one launch, back to back: `per_graph` launches captured in a hipGraph (the host's launch
         rate -- ~7 us per ctypes call -- would otherwise be what is measured), replayed reps / per_graph times between
@@ -217,7 +218,7 @@ def main():
         e1.synchronize()
         return e0.elapsed_time(e1) / (reps // per_graph * per_graph) * 1e-3
 
-    if rank == 0:
+    if True:   # every rank (the same untimed work everywhere: no rank waits for another in the first collective)
         v0, y0 = data_v[0], data_y[0]
         ph0, h, vk, yk, phk = ws[:5]
         ng = _lib.RbmGrads(None, ptr(G.gb), ptr(G.gd), ptr(G.gU), ptr(G.gc))
@@ -318,8 +319,8 @@ def main():
             "config": {"workload": "ClassificationRBM 784v x 512h, C=10, CD-1, batch 256 per GPU (BASELINE.json configs[3] shape; "
                                    "global batch 256*N, RCCL all-reduce of the flat gradient per step when N>1)",
                        "batch_per_gpu": B, "cd_k": K_CD, "warmup_steps_run": warm_steps,
-                       "pre_timed_kernel_launches": (1000 + 55 + 5) * len(timed) if rank == 0 else 0,
-                       "launches_per_step": "k_hidden, k_visible, k_hgrad" if (rank == 0 and any("k_hgrad" in k for k in timed)) else "k_hidden, k_visible, k_hidden, k_grad (+ all-reduce, k_update when data-parallel)",
+                       "pre_timed_kernel_launches": (1000 + 55 + 5) * len(timed),
+                       "launches_per_step": "k_hidden, k_visible, k_hgrad" if any("k_hgrad" in k for k in timed) else "k_hidden, k_visible, k_hidden, k_grad (+ all-reduce, k_update when data-parallel)",
                        "draws": "a replayed graph repeats the draw ids and minibatches it captured (same work per step)" if graphs else "fresh draw ids per step", "launch": (f"hipGraph x{graphs[1]} steps" if graphs else "eager") + (f" ({graph_note})" if graph_note else ""),
                        "parallelism": f"dp{world}" + (" (forced data-parallel path)" if args.force_dp and world == 1 else "")},
             "visible_unit_updates_per_sec": round(value * V, 1),

@@ -98,6 +98,27 @@ class Disc_QBM:
     biases_hidden = property(lambda s: s._get("_bh"), lambda s, v: s._set("_bh", v))                            # [H]
     biases_output = property(lambda s: s._get("_bo"), lambda s, v: s._set("_bo", v))                            # [1]
 
+    # W_hh never learns and beta_eff is a constructor constant, but both are public attributes of
+    # the reference: assigning them drops what was derived from the old value (the uploaded W_hh, the cached couplings)
+    @property
+    def weights_hidden_hidden(self):
+        return self._whh
+
+    @weights_hidden_hidden.setter
+    def weights_hidden_hidden(self, value):
+        self._whh = value
+        self._whh_dev = None
+        self._J_cache = {}
+
+    @property
+    def beta_eff(self):
+        return self._beta_eff
+
+    @beta_eff.setter
+    def beta_eff(self, value):
+        self._beta_eff = value
+        self._J_cache = {}
+
     @property
     def weight_objects(self):
         """The reference's pickle layout (:88-95), built from the CURRENT arrays (the reference builds the list once, so a
@@ -445,25 +466,38 @@ class Disc_QBM:
             batchnum = 1
             num_batches = max(1, n_train // batch_size)
             errs, nlls = [], []
-            for b in range(0, n_train, batch_size):
-                xb, yb = Xd[b:b + batch_size], Yd[b:b + batch_size]       # the last partial batch is kept (:1106-1111)
-                if xb.shape[0] == 0:
-                    continue
-                try:
+            import torch
+
+            def flush():   # the epoch's ONE synchronisation: per-batch error / NLL to the host (what has been enqueued so far)
+                e = torch.stack(errs).cpu().tolist() if errs else []
+                n = torch.stack(nlls).cpu().tolist() if nlls else []
+                return e, n
+
+            try:
+                for b in range(0, n_train, batch_size):
+                    xb, yb = Xd[b:b + batch_size], Yd[b:b + batch_size]       # the last partial batch is kept (:1106-1111)
+                    if xb.shape[0] == 0:
+                        continue
                     err_bo, avg_nll = self._step_device(xb, yb, learning_rate)
                     errs.append(err_bo)
                     nlls.append(avg_nll)
                     batchnum += 1
-                except Exception:
-                    # dump-on-exception, then re-raise (:1128-1132)
-                    if rank == 0:
+                errs_h, nlls_h = flush()      # inside the try: an asynchronous device failure surfaces HERE
+            except Exception:
+                # dump-on-exception, then re-raise (:1128-1132): weights, and the history with what this epoch has of it
+                if rank == 0:
+                    try:
+                        e_part, n_part = flush()
+                        self.training_history.errors_per_batch.extend(e_part)
+                        self.training_history.nll_per_batch.extend(n_part)
+                    except Exception:   # noqa: BLE001 -- the device is gone: dump what the host has
+                        pass
+                    try:
                         self.save_weights(f'e{epoch}_b{batchnum}_{self.param_string}', save_folder)
-                        metrics.save_history(f"{save_folder}/", self.training_history)
-                    raise
-            import torch
-
-            errs_h = torch.stack(errs).cpu().tolist() if errs else []        # ONE synchronisation per epoch
-            nlls_h = torch.stack(nlls).cpu().tolist() if nlls else []
+                    except Exception:   # noqa: BLE001
+                        pass
+                    metrics.save_history(f"{save_folder}/", self.training_history)
+                raise
             self.training_history.errors_per_batch.extend(errs_h)             # np.mean of a 1-element array = the element
             self.training_history.nll_per_batch.extend(nlls_h)
             epoch_errors, epoch_nll = float(np.sum(errs_h)), float(np.sum(nlls_h))

@@ -133,3 +133,40 @@ def test_couplings_match_reference_qubo_offdiagonals():
     off = g["Q_unclamped"][0] - np.diag(np.diag(g["Q_unclamped"][0]))
     want = (off + off.T) * float(g["beta_eff"]) / 2.0
     assert np.allclose(q3._couplings(False), want, rtol=1e-7, atol=0)
+
+
+def test_train_model_dumps_weights_and_history_when_a_step_fails(tmp_path):
+    """src/model/faster_dqbm.py:1128-1132: an exception inside the training loop saves the weights and the history before it
+    is re-raised -- including the per-batch error / NLL of the minibatches of the CURRENT epoch that did complete (they live
+    on the device until the epoch's one synchronisation: ADVICE round 2)."""
+    import os
+
+    g = golden("qbm_small.npz")
+    q = make(g, ops=OracleQuboOps())
+    q.speicherort, q.param_string, q.epochs = str(tmp_path) + "/", "boom", 2
+    X, Y = g["X"], g["Y"]
+    real, calls = q._step_device, [0]
+
+    def flaky(xb, yb, lr):
+        calls[0] += 1
+        if calls[0] == 3:
+            raise RuntimeError("device lost")
+        return real(xb, yb, lr)
+
+    q._step_device = flaky
+    with pytest.raises(RuntimeError, match="device lost"):
+        q.train_model(X, Y, X, Y, batch_size=1, learning_rate=0.1)
+    assert len(q.training_history.nll_per_batch) == 2 and len(q.training_history.errors_per_batch) == 2
+    files = os.listdir(str(tmp_path) + "/boom")
+    assert any(f.startswith("e1_b3_boom") for f in files), files          # weights at the failing minibatch
+
+
+def test_assigning_w_hh_or_beta_eff_drops_the_derived_caches():
+    g = golden("qbm_small.npz")
+    q = make(g, ops=OracleQuboOps())
+    q._whh_dev, q._J_cache = "stale", {True: "stale", False: "stale"}
+    q.weights_hidden_hidden = q.weights_hidden_hidden * 2.0
+    assert q._whh_dev is None and q._J_cache == {}
+    q._J_cache = {True: "stale"}
+    q.beta_eff = 2.0
+    assert q._J_cache == {} and q.beta_eff == 2.0

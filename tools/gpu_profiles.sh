@@ -16,7 +16,7 @@ stats bench python3 $ROOT/bench.py --steps 800 --warmup 80 --no-cpu-baseline    
 cp $ROOT/gpurun_out/prof_bench.out $OUT/${R}_bench_under_rocprof.json
 stats other_configs python3 $ROOT/tools/bench_configs.py
 cp $ROOT/gpurun_out/prof_other_configs.out $OUT/${R}_other_configs_under_rocprof.jsonl
-stats train_loop python3 $ROOT/tools/bench_train_loop.py --reps 1      # one epoch each of ClassificationRBM.train_rbm (3 rules) / Disc_QBM.train_model
+stats train_loop python3 $ROOT/tools/bench_train_loop.py --reps 1 --no-dp      # one epoch each of ClassificationRBM.train_rbm (3 rules) / Disc_QBM.train_model
 cp $ROOT/gpurun_out/prof_train_loop.out $OUT/${R}_train_loop_under_rocprof.jsonl
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU" "GRBM_GUI_ACTIVE"; do
   tag=$(echo $set | cut -d' ' -f1); rm -rf $ROOT/gpurun_out/pmc_$tag
