@@ -516,6 +516,9 @@ __global__ __launch_bounds__(64 * V_NQ) void k_visible(VisibleArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int nMs = (a.B + 16 * V_MT - 1) / (16 * V_MT), nNs = (a.V + 16 * V_NT - 1) / (16 * V_NT);
+    // aux workgroups in front of the strips (or none): the strips' part of the grid is padded so that the row strips that
+    // read one block of W rows share an XCD for ANY number of visible strips (49 at V = 784: strip_coords_padded)
+    const bool padded = a.n_aux == a.B || a.n_aux == 0;
     {   // aux workgroups behind a fused launch that gave up: nothing to do (the strips test the word in front of their stores)
         const bool is_aux = a.n_aux == a.B ? (int)blockIdx.x < a.n_aux + a.n_fe : (int)blockIdx.x >= nMs * nNs;
         if (a.n_aux > 0 && is_aux && a.status && *a.status != 0u) return;
@@ -537,7 +540,7 @@ __global__ __launch_bounds__(64 * V_NQ) void k_visible(VisibleArgs a)
                                 a.fe_rowloss, (int)threadIdx.x, V_NQ, reinterpret_cast<float*>(lds));
             return;
         }
-    } else if ((int)blockIdx.x >= nMs * nNs) {
+    } else if (!padded && (int)blockIdx.x >= nMs * nNs) {
         // large minibatches: 8 rows per aux workgroup, one per wavefront, dealt BEHIND the strips (they fill the ragged end of
         // the launch instead of standing in front of it)
         const int i = ((int)blockIdx.x - nMs * nNs) * V_NQ + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -549,7 +552,11 @@ __global__ __launch_bounds__(64 * V_NQ) void k_visible(VisibleArgs a)
     asm volatile("" ::"s"(a.h), "s"(a.W), "s"(a.b), "s"(a.p), "s"(a.s), "s"(a.s8), "s"(a.B), "s"(a.V), "s"(a.H), "s"(a.KP),
                  "s"(a.seed), "s"(a.offset), "s"(a.row0));   // all arguments in one scalar-cache round trip (see k_hidden)
     int ms, ns;
-    strip_coords(nMs, nNs, ms, ns, a.n_aux == a.B ? a.n_aux + a.n_fe : 0);
+    if (padded) {
+        if (!strip_coords_padded(nMs, nNs, ms, ns, a.n_aux + a.n_fe)) return;
+    } else {
+        strip_coords(nMs, nNs, ms, ns, 0);
+    }
     visible_body<TA, FAST, V_MT, V_NT>(a, ms, ns, lds);
 }
 
@@ -1766,7 +1773,7 @@ int launch_visible_t(const qbm_rbm_params* P, const void* h, int B, float* p_v, 
     }
     const bool fast = (P->H % 16 == 0) && aligned16(h) && aligned16(P->W) && small2g((long)B * P->H, ASZ) &&
                       small2g((long)P->V * P->H, 4);
-    const int grid = nM * nN + a.n_aux + a.n_fe;
+    const int grid = ((a.n_aux == B || a.n_aux == 0) ? strip_grid_padded(nM, nN) : nM * nN) + a.n_aux + a.n_fe;
     const size_t lds = strip_lds_bytes<MT, NT, ASZ, NQ>(a.KP);   // (>= the aux workgroups' few hundred bytes)
 #define QBM_LAUNCH(F, CM)                                                                       \
     {                                                                                           \

@@ -866,6 +866,18 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
 // Speed-only remap of blockIdx -> (m strip, n strip): workgroups that read the same B panel
 // (same n strip) are dealt to the same XCD (blocks b and b+8 share one), so that each XCD's L2
 // holds 1/8 of the B operand.  Falls back to the plain map when nN is not a multiple of 8.
+// The same for any nN, on a grid padded to 8 * nM * ceil(nN / 8) strips workgroups (strip_grid_padded): XCD x takes the n
+// strips x, x + 8, ... with all their m strips; false = a workgroup of the padding (nothing to do).
+__host__ __device__ __forceinline__ int strip_grid_padded(int nM, int nN) { return 8 * nM * ((nN + 7) / 8); }
+__device__ __forceinline__ bool strip_coords_padded(int nM, int nN, int& ms, int& ns, int first = 0)
+{
+    const int id = (int)blockIdx.x - first;
+    const int x = id & 7, j = id >> 3;
+    ns = x + 8 * (j / nM);
+    ms = j % nM;
+    return ns < nN;
+}
+
 __device__ __forceinline__ void strip_coords(int nM, int nN, int& ms, int& ns, int first = 0)
 {
     const int id = (int)blockIdx.x - first;  // `first` aux workgroups precede the strips in the grid
