@@ -902,7 +902,8 @@ struct GradArgs {
     float* n_rows;                               // non-null: receives (float)B -- the data-parallel path all-reduces it with the
                                                  // gradients -- or -inf when `status` is set (every rank then skips the update)
     // discriminative step (kind D workgroups, BEHIND the strips in the grid; P1 == null: one phase only)
-    int nD;                                      // workgroups of kind D: C x ceil(H / 16)
+    int nD;                                      // workgroups of kind D: C x ceil(ceil(H / 16) / dW)
+    int dW;                                      // blocks of 16 hidden columns per kind D workgroup
     const float* pre; const float* Up; const float* pyx; const int* labels;   // x.W + d [B,H], U [C,H], p(y|x) [B,C], labels [B]
     const float* rowloss;                        // [B,2] per-row loss terms (k_free_energy) or null
     double* loss_acc;                            // non-null: [2] running sums of the per-minibatch means of the two loss terms
@@ -987,7 +988,7 @@ __device__ __forceinline__ void loss_block(const GradArgs& a, char* lds_raw)
 // (quarter q, column) walks its quarter's rows in order -- fmaf(onehot, o, acc) for the first sum (bit for bit the chain of
 // the [onehot]^T.pos contraction: rows of another class enter as 0 * o), fmaf(1, o * p, acc) for the second.
 // Fused update of U, c and of the gradient-free visible bias (:138: grad 0, the sparsity constant still applies).
-__device__ __forceinline__ void disc_class_block(const GradArgs& a, int blk, char* lds_raw)
+__device__ __forceinline__ void disc_class_block1(const GradArgs& a, int c, int jb, bool sweep_b, int blk, char* lds_raw)
 {
     float (*o_s)[17] = reinterpret_cast<float (*)[17]>(lds_raw);
     float* pc_s = reinterpret_cast<float*>(lds_raw) + 256 * 17;
@@ -996,8 +997,6 @@ __device__ __forceinline__ void disc_class_block(const GradArgs& a, int blk, cha
     float* nl_s = ce_s + 256;
     float (*part)[40] = reinterpret_cast<float (*)[40]>(nl_s + 256);   // [4 quarters][16 A | 16 B | onehot | p | ce | nll]
     const int B = a.B, H = a.H, C = a.C;
-    const int nJ = (H + 15) / 16;
-    const int c = blk / nJ, jb = blk % nJ;
     const int tid = (int)threadIdx.x;
     const int col = tid & 15, slot = tid >> 4;
     const int j = jb * 16 + col, jj = min(j, H - 1);
@@ -1057,8 +1056,21 @@ __device__ __forceinline__ void disc_class_block(const GradArgs& a, int blk, cha
             a.loss_acc[1] = a.loss_acc[1] + (double)(qsum(35) / (float)B);
         }
     }
-    if (a.dub)
+    if (a.dub && sweep_b)
         for (int m = blk * 256 + tid; m < a.V; m += a.nD * 256) a.dub[m] = upd(a.dub[m], 0.f, a, true);
+}
+
+// Workgroup `blk` of kind D: class c, a.dW consecutive blocks of 16 hidden columns, one after the other.  (a.dW > 1 where the
+// gradient launch holds ONE workgroup per CU -- fp32 inputs: 96 KB of staging -- and C * H / 16 workgroups of kind D would
+// queue up behind the strips for further rounds: fewer, longer ones finish beside the strips, on the CUs the strips leave free.)
+__device__ __forceinline__ void disc_class_block(const GradArgs& a, int blk, char* lds_raw)
+{
+    const int nJ = (a.H + 15) / 16, nJw = (nJ + a.dW - 1) / a.dW;
+    const int c = blk / nJw, jb0 = (blk % nJw) * a.dW;
+    for (int w = 0; w < a.dW && jb0 + w < nJ; ++w) {
+        if (w) __syncthreads();   // the block before has consumed its LDS arrays
+        disc_class_block1(a, c, jb0 + w, w == 0, blk, lds_raw);
+    }
 }
 
 // Epilogues of the small gradient blocks (o0 / o1: the two phases' strips as the finishing thread holds them).
@@ -1825,10 +1837,20 @@ int launch_grad_t(int V, int H, int C, int B, const void* A0, const float* Y0, c
                lr, factor, bs, sparse, B, V, H, C, panel_for<MT, NT, 4>(B),
                nN, want_b ? nM : 0, want_c ? (C + 16 * NT - 1) / (16 * NT) : 0,
                (H % 4 == 0) && (!G->gW || aligned16(G->gW)) && (!W_fused || aligned16(W_fused)), gU_sub, 0, 0, 0, status, G->n_rows,
-               0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+               0, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (mon_rowloss && mon_loss_acc) { a.nL = 1; a.rowloss = mon_rowloss; a.loss_acc = mon_loss_acc; }
     if (dx) {
-        a.nD = C * ((H + 15) / 16);
+        const int nJ = (H + 15) / 16;
+        // one workgroup per CU (an fp32 operand: 96 KB of staging): as many kind D workgroups as CUs the strips leave free, if
+        // 2 or 4 column blocks per workgroup get there (C = 2 at H = 512: 16 workgroups of 4 blocks beside 238 others: 25.1 us
+        // per step instead of 26.5; 8 blocks -- C = 4 -- take longer than the strips beside them: 35 us instead of 28)
+        const bool one_per_cu = !(sizeof(T0) == 1 && sizeof(T1) == 1);
+        const int others = a.nU + a.nB + a.nC + nM * nN;
+        a.dW = 1;
+        if (one_per_cu && others < 256 && C * nJ > 256 - others)
+            for (int w = 2; w <= 4; w *= 2)
+                if (C * ((nJ + w - 1) / w) <= 256 - others) { a.dW = w; break; }
+        a.nD = C * ((nJ + a.dW - 1) / a.dW);
         a.pre = dx->pre; a.Up = dx->U; a.pyx = dx->pyx; a.labels = dx->labels; a.rowloss = dx->rowloss; a.loss_acc = dx->loss_acc;
         a.dgU = dx->dgU; a.dgc = dx->dgc; a.duU = dx->duU; a.duc = dx->duc; a.dub = dx->dub;
     }
@@ -2012,7 +2034,7 @@ int launch_hgrad(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void* v0
                 fuse_update ? P->c : nullptr, lr, factor, bs, sparse, B, V, H, C, 64,
                 0, want_b ? 1 : 0, want_c ? 1 : 0,
                 (H % 4 == 0) && (!g.gW || aligned16(g.gW)) && aligned16(P->W), nullptr, 0, 0, 0, nullptr, G->n_rows,
-                0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+                0, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (mon_rowloss && mon_loss_acc) { ga.nL = 1; ga.rowloss = mon_rowloss; ga.loss_acc = mon_loss_acc; }
     // LDS.  Items that go in one call: a staging region per thread group, sized for the largest kind (see launch_grad_t).
     size_t grp = strip_lds_bytes<HG_MT, H_NT, 1>(ga.KP);
