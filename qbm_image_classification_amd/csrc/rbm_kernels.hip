@@ -410,7 +410,8 @@ template <int CM>
 __device__ __forceinline__ void free_energy_row(const float* __restrict__ pre, const float* __restrict__ U,
                                                 const float* __restrict__ cb, float* __restrict__ negF, float* __restrict__ p_out,
                                                 int i, int H, int C, const int* __restrict__ labels, float* __restrict__ diff,
-                                                float* __restrict__ rowloss, int tid, int nw, float* __restrict__ sm);
+                                                float* __restrict__ rowloss, int tid, int nw, float* __restrict__ sm,
+                                                float* __restrict__ sp_lds = nullptr);
 
 // ---------------------------------------------------------------------------------------------
 // A-2  sample_visible  (src/ClassificationRBM.py:49-52):  p = sigma(h.W^T + b);  v = (p > u)
@@ -439,6 +440,7 @@ struct VisibleArgs {
     // the training loop's monitor riding along (qbm_rbm_cd_workspace.mon_*): n_fe = B more aux workgroups behind the class
     // rows, one row each: -F, p(y|x0) and the row's two loss terms from x0.W + d (stored by the launch in front)
     int n_fe; const float* fe_pre; const int* fe_labels; float* fe_p; float* fe_rowloss;
+    int fe_stage;             // the softplus terms of a monitor row staged through LDS (they fit behind the row's small arrays)
     uint32_t* hg_round;       // non-null: the fused tail of the step (k_hgrad) is the next launch: this one advances the word
                               // that launch takes its barrier round from (one writer, a kernel boundary in front of the readers:
                               // the same number in every workgroup whatever shapes earlier launches on the buffer had)
@@ -536,8 +538,9 @@ __global__ __launch_bounds__(64 * V_NQ) void k_visible(VisibleArgs a)
         if ((int)blockIdx.x < a.n_aux + a.n_fe) {   // the monitor: one row per workgroup, its classes dealt to the 8 wavefronts (in
                                                     // front of the strips: behind them -- the ragged end of the launch -- they
                                                     // start late and the launch ends 4.8 us later; measured)
+            float* sm = reinterpret_cast<float*>(lds);   // [small arrays: (2 + CM)(CM + 1) <= 272 floats | staged softplus terms C x H, if they fit]
             free_energy_row<CM>(a.fe_pre, a.U, a.cb, nullptr, a.fe_p, (int)blockIdx.x - a.n_aux, a.H, a.C, a.fe_labels, nullptr,
-                                a.fe_rowloss, (int)threadIdx.x, V_NQ, reinterpret_cast<float*>(lds));
+                                a.fe_rowloss, (int)threadIdx.x, V_NQ, sm, a.fe_stage ? sm + 320 : nullptr);
             return;
         }
     } else if (!padded && (int)blockIdx.x >= nMs * nNs) {
@@ -733,7 +736,7 @@ __global__ __launch_bounds__(512) void k_chain(ChainArgs a)
         } else {
             if (j < nNv) {
                 const VisibleArgs va{a.h, a.W, a.b, nullptr, nullptr, vout, a.B, a.V, a.H, a.KPv, a.seed, off - 2, a.row0, a.vecO,
-                                     a.U, a.c, nullptr, yout, a.C, off - 1, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+                                     a.U, a.c, nullptr, yout, a.C, off - 1, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
                 visible_body<uint8_t, true, 2, 2, kSc1>(va, g, j, lds + a.ldsT);
             }
             // class conditional of the block's 32 rows, one row per wavefront, on the workgroups that have no strip -- or,
@@ -770,7 +773,8 @@ template <int CM>
 __device__ __forceinline__ void free_energy_row(const float* __restrict__ pre, const float* __restrict__ U,
                                                 const float* __restrict__ cb, float* __restrict__ negF, float* __restrict__ p_out,
                                                 int i, int H, int C, const int* __restrict__ labels, float* __restrict__ diff,
-                                                float* __restrict__ rowloss, int tid, int nw, float* __restrict__ sm)
+                                                float* __restrict__ rowloss, int tid, int nw, float* __restrict__ sm,
+                                                float* __restrict__ sp_lds)
 {
     float* nf_s = sm;
     float* p_s = sm + (CM + 1);
@@ -778,11 +782,26 @@ __device__ __forceinline__ void free_energy_row(const float* __restrict__ pre, c
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lab = labels ? labels[i] : 0;
+    // sp_lds ([C][H] floats of LDS, or null): the softplus terms -- the expensive part -- are evaluated by ALL threads of the
+    // team into LDS first, and each class's wavefront then only walks its chain over them (same values, same order: [T]).
+    // Pays when the team has more wavefronts than classes (C = 2 with 8 wavefronts: 2 evaluations per thread instead of 8 on
+    // two wavefronts).
+    if (sp_lds) {
+        for (int idx = tid; idx < C * H; idx += 64 * nw) {
+            const int cls = idx / H, j = idx - cls * H;
+            sp_lds[idx] = det_softplus(pre[(long)i * H + j] + U[(long)cls * H + j]);
+        }
+        __syncthreads();
+    }
     for (int cls = w; cls < C; cls += nw) {
         float nf = 0.f;
         const float cbv = cb[cls];
         const float* prow = pre + (long)i * H;
         const float* urow = U + (long)cls * H;
+        if (sp_lds) {
+            const float* sp = sp_lds + cls * H;
+            for (int j = lane; j < H; j += kWave) nf = nf + sp[j];
+        } else
         for (int jb = 0; jb < H; jb += 8 * kWave) {   // the lane chains j = lane, lane + 64, ... ascending ([T])
             float pv[8], uv[8];
 #pragma unroll
@@ -845,16 +864,33 @@ __device__ __forceinline__ void free_energy_row(const float* __restrict__ pre, c
     }
 }
 
+// blockDim = 64 * max(C, kFeMinWaves): at least 8 wavefronts per row (with fewer classes the spare ones evaluate softplus
+// terms and the discriminative step's `diff` columns); dynamic LDS: C * H floats for the staged softplus terms, or 0
+constexpr int kFeMinWaves = 8;
 template <int CM>
-__global__ __launch_bounds__(64 * CM) void k_free_energy(const float* __restrict__ pre, const float* __restrict__ U,
-                                                         const float* __restrict__ cb, float* __restrict__ negF,
-                                                         float* __restrict__ p_out, int B, int H, int C,
-                                                         const int* __restrict__ labels, float* __restrict__ diff,
-                                                         float* __restrict__ rowloss, const uint32_t* __restrict__ status)
+__global__ __launch_bounds__(64 * (CM > kFeMinWaves ? CM : kFeMinWaves)) void k_free_energy(
+    const float* __restrict__ pre, const float* __restrict__ U, const float* __restrict__ cb, float* __restrict__ negF,
+    float* __restrict__ p_out, int B, int H, int C, const int* __restrict__ labels, float* __restrict__ diff,
+    float* __restrict__ rowloss, const uint32_t* __restrict__ status, int stage_sp)
 {
     if (status && *status != 0u) return;   // (the CD step's monitor behind a fused launch that gave up: HiddenArgs::status)
+    extern __shared__ __attribute__((aligned(16))) float sp_dyn[];
     __shared__ float sm[(2 + CM) * (CM + 1)];
-    free_energy_row<CM>(pre, U, cb, negF, p_out, (int)blockIdx.x, H, C, labels, diff, rowloss, (int)threadIdx.x, (int)(blockDim.x >> 6), sm);
+    free_energy_row<CM>(pre, U, cb, negF, p_out, (int)blockIdx.x, H, C, labels, diff, rowloss, (int)threadIdx.x, (int)(blockDim.x >> 6), sm,
+                        stage_sp ? sp_dyn : nullptr);
+}
+
+// launch of k_free_energy: 8 wavefronts at least; the softplus terms staged through LDS when the team has spare wavefronts
+// (C < 8) and they fit
+template <int CM>
+void launch_free_energy(const float* pre, const float* U, const float* cb, float* negF, float* p_out, int B, int H, int C,
+                        const int* labels, float* diff, float* rowloss, const uint32_t* status, hipStream_t st)
+{
+    const int waves = C > kFeMinWaves ? C : kFeMinWaves;
+    const size_t sp_bytes = (size_t)C * H * sizeof(float);
+    const int stage = (C < kFeMinWaves && sp_bytes <= 49152) ? 1 : 0;
+    hipLaunchKernelGGL((k_free_energy<CM>), dim3(B), dim3(64 * waves), stage ? sp_bytes : 0, st, pre, U, cb, negF, p_out, B, H, C,
+                       labels, diff, rowloss, status, stage);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1778,7 +1814,7 @@ int launch_visible_t(const qbm_rbm_params* P, const void* h, int B, float* p_v, 
                   // pairs of visible units: 8-byte accesses to p / v_f32 / b, 2-byte accesses to v_u8
                   (P->V % 2 == 0) && (!p_v || aligned8(p_v)) && (!v_s || aligned8(v_s)) && (!v_s8 || aligned2(v_s8)) &&
                       aligned8(P->b),
-                  P->U, P->c, p_y, y1hot, P->C, offset_y, with_class ? (B <= 512 ? B : (B + NQ - 1) / NQ) : 0, status, 0, nullptr, nullptr, nullptr, nullptr,
+                  P->U, P->c, p_y, y1hot, P->C, offset_y, with_class ? (B <= 512 ? B : (B + NQ - 1) / NQ) : 0, status, 0, nullptr, nullptr, nullptr, nullptr, 0,
                   status ? hg_round : nullptr};
     if (mon && a.n_aux == B) {   // (visible_takes_monitor: the caller has asked)
         a.n_fe = B; a.fe_pre = mon->mon_pre; a.fe_labels = mon->mon_labels; a.fe_p = mon->mon_p; a.fe_rowloss = mon->mon_rowloss;
@@ -1787,6 +1823,9 @@ int launch_visible_t(const qbm_rbm_params* P, const void* h, int B, float* p_v, 
                       small2g((long)P->V * P->H, 4);
     const int grid = ((a.n_aux == B || a.n_aux == 0) ? strip_grid_padded(nM, nN) : nM * nN) + a.n_aux + a.n_fe;
     const size_t lds = strip_lds_bytes<MT, NT, ASZ, NQ>(a.KP);   // (>= the aux workgroups' few hundred bytes)
+    // (only with fewer classes than wavefronts: at C = 10 the staged form costs the step 0.7 us more than two classes on two of
+    // the wavefronts -- measured)
+    a.fe_stage = a.n_fe > 0 && P->C < NQ && 1280 + (size_t)P->C * P->H * sizeof(float) <= lds;
 #define QBM_LAUNCH(F, CM)                                                                       \
     {                                                                                           \
         if (int rc = set_lds(k_visible<TA, F, CM>, lds)) return rc;                             \
@@ -2161,9 +2200,8 @@ int qbm_rbm_free_energy(const qbm_rbm_params* P, const float* x, int B, float* p
     if (!x || !pre_ws || (!neg_free_energy && !p_y_given_x)) return fail(QBM_ERR_ARG, "free_energy: null buffer");
     if (int rc = launch_hidden(P, x, QBM_F32, nullptr, B, pre_ws, nullptr, nullptr, 1, 0, 0, 0, (hipStream_t)stream)) return rc;
 #define QBM_L(CM)                                                                                               \
-    hipLaunchKernelGGL((k_free_energy<CM>), dim3(B), dim3(64 * P->C), 0, (hipStream_t)stream, pre_ws, P->U,             \
-                       P->c, neg_free_energy, p_y_given_x, B, P->H, P->C, (const int*)nullptr, (float*)nullptr,   \
-                       (float*)nullptr, (const uint32_t*)nullptr)
+    launch_free_energy<CM>(pre_ws, P->U, P->c, neg_free_energy, p_y_given_x, B, P->H, P->C, nullptr, nullptr, nullptr,  \
+                           nullptr, (hipStream_t)stream)
     QBM_DISPATCH_CM(P->C, QBM_L);
 #undef QBM_L
     QBM_CHECK_LAUNCH("k_free_energy");
@@ -2306,9 +2344,8 @@ int qbm_rbm_cd_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void*
         // the one-launch chain does not deliver v0.W + d: one contraction of its own
         if (fused)
             if (int rc = launch_hidden(P, v0, v0_dtype, nullptr, B, ws->mon_pre, nullptr, nullptr, 1, 0, 0, 0, st)) return rc;
-#define QBM_L(CM)                                                                                                         \
-    hipLaunchKernelGGL((k_free_energy<CM>), dim3(B), dim3(64 * P->C), 0, st, ws->mon_pre, P->U, P->c, (float*)nullptr, ws->mon_p, \
-                       B, P->H, P->C, ws->mon_labels, (float*)nullptr, ws->mon_rowloss, hg_status)
+#define QBM_L(CM) \
+    launch_free_energy<CM>(ws->mon_pre, P->U, P->c, nullptr, ws->mon_p, B, P->H, P->C, ws->mon_labels, nullptr, ws->mon_rowloss, hg_status, st)
         QBM_DISPATCH_CM(P->C, QBM_L);
 #undef QBM_L
         QBM_CHECK_LAUNCH("k_free_energy");
@@ -2402,9 +2439,8 @@ int qbm_rbm_disc_step_ex(const qbm_rbm_params* P, const qbm_rbm_grads* G, const 
     //      (kind D workgroups, behind the strips: sigma(pre + U_c) is evaluated there once more rather than stored as a
     //      [B,C,H] array); every update fused
     if (int rc = launch_hidden(P, x, x_dtype, nullptr, B, ws->pre, nullptr, nullptr, 1, 0, 0, 0, st)) return rc;
-#define QBM_L(CM)                                                                                               \
-    hipLaunchKernelGGL((k_free_energy<CM>), dim3(B), dim3(64 * P->C), 0, st, ws->pre, P->U, P->c, neg_free_energy, p_y, \
-                       B, P->H, P->C, labels, ws->diff, ws->rowloss, (const uint32_t*)nullptr)
+#define QBM_L(CM) \
+    launch_free_energy<CM>(ws->pre, P->U, P->c, neg_free_energy, p_y, B, P->H, P->C, labels, ws->diff, ws->rowloss, nullptr, st)
     QBM_DISPATCH_CM(P->C, QBM_L);
 #undef QBM_L
     QBM_CHECK_LAUNCH("k_free_energy");
