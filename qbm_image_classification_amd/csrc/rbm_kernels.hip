@@ -41,7 +41,13 @@ constexpr int H_MT = QBM_H_MT, H_NT = QBM_H_NT;
 #define QBM_V_MT 4
 #endif
 constexpr int V_MT = QBM_V_MT, V_NT = 1;
-constexpr int G_MT = 4, G_NT = 2;
+// Gradient strips: 64 rows x 32 hidden columns (NT = 2) for the two-phase form at the benchmark shape; 64 x 16 (NT = 1) for the
+// one-phase form of the discriminative step (its fp32 operand then needs 80 KB instead of 96 KB of LDS: TWO workgroups per
+// CU, and the kind D workgroups run beside the strips: 784 x 512, B = 256, C = 10: 32.4 -> 26.8 us per step) and wherever the
+// wider strips leave half of the CUs without a workgroup (784 x 128: 22.8 -> 21.7 us per CD-1 step).  Measured the other way
+// round too: 64 x 16 strips for the two-phase form at 784 x 512 cost 9.6 instead of 8.5 us per launch (every data tile is
+// staged twice as often), B = 2048: 135 instead of 126 us per step.
+constexpr int G_MT = 4;
 
 // class-count buckets for the kernels that keep one register (or one float4) per class
 #define QBM_DISPATCH_CM(C, MACRO)                   \
@@ -1202,39 +1208,57 @@ __device__ __forceinline__ float4 grad_w_tile(const GradArgs& a, int m0, int n0,
 }
 
 // The (16 MT) x (16 NT) strip of gW at (m0, n0), both phases side by side (uint8 data, 512 threads: see below).
+// The two groups share the epilogue.  NP == 2 outputs per thread: output 0 of every thread is finished by group 0, output 1 by
+// group 1.  NP == 1 (a strip of 256 float4 outputs): thread t's output is finished by group t / 128 -- half of each group's
+// threads finish, the others only hand their partial over.
 template <int MT, int NT, bool FAST>
 __device__ __forceinline__ void grad_w_strip_par(const GradArgs& a, int m0, int n0, char* lds_all, int grp)
 {
     using SO = StripOut<MT, NT>;
-    static_assert(SO::NP == 2, "the two groups share the epilogue, output 0 of every thread to group 0, output 1 to group 1");
+    static_assert(SO::NP == 2 || SO::NP == 1, "the two groups share the epilogue");
     char* lds = lds_all + (size_t)grp * a.lds_group;
     const ViewCContig P0{a.P0, a.H, a.H, a.B}, P1{a.P1, a.H, a.H, a.B};
     const ViewCContigU8 D0{reinterpret_cast<const uint8_t*>(a.A0), a.V, a.V, a.B}, D1{reinterpret_cast<const uint8_t*>(a.A1), a.V, a.V, a.B};
-    // group 0 finishes output 0 and needs phase 1's output 0; group 1 finishes output 1 and needs phase 0's output 1
     const bool first = grp == 0;
+    const int t = (int)threadIdx.x & 255;
+    const bool mine_to_finish = SO::NP == 2 || (t >> 7) == grp;      // (NP == 1) do I finish my output, or hand it over?
+    constexpr int kOp1 = SO::NP == 2 ? 1 : 0;                        // group 1's output among a thread's
     float4 w_old = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto pre0 = [&]() { w_old = first ? grad_w_tile<SO>(a, m0, n0, 0) : grad_w_tile<SO>(a, m0, n0, 1); };
+    auto pre0 = [&]() {
+        if (mine_to_finish) w_old = first ? grad_w_tile<SO>(a, m0, n0, 0) : grad_w_tile<SO>(a, m0, n0, kOp1);
+    };
     QBM_STAMP(11);
     SO mine;
     if (first) mine = strip_mma<MT, NT, FAST, FAST>(D0, P0, m0, n0, a.B, lds, a.KP, pre0);
     else mine = strip_mma<MT, NT, FAST, FAST>(D1, P1, m0, n0, a.B, lds, a.KP, pre0, NoPre{}, 5);
-    const float4 keep = first ? mine.sum[0] : mine.sum[1], give = first ? mine.sum[1] : mine.sum[0];
     float4* x = reinterpret_cast<float4*>(lds_all);   // every thread has left strip_mma: the staging regions are free
-    x[grp * 256 + ((int)threadIdx.x & 255)] = give;
-    __syncthreads();
-    const float4 got = x[(1 - grp) * 256 + ((int)threadIdx.x & 255)];
-    if (first) grad_finish_w<SO>(a, m0, n0, 0, keep, got, w_old);
-    else grad_finish_w<SO>(a, m0, n0, 1, got, keep, w_old);
+    if constexpr (SO::NP == 2) {
+        // group 0 finishes output 0 and needs phase 1's output 0; group 1 finishes output 1 and needs phase 0's output 1
+        const float4 keep = first ? mine.sum[0] : mine.sum[1], give = first ? mine.sum[1] : mine.sum[0];
+        x[grp * 256 + t] = give;
+        __syncthreads();
+        const float4 got = x[(1 - grp) * 256 + t];
+        if (first) grad_finish_w<SO>(a, m0, n0, 0, keep, got, w_old);
+        else grad_finish_w<SO>(a, m0, n0, 1, got, keep, w_old);
+    } else {
+        if (!mine_to_finish) x[t] = mine.sum[0];      // (slot t is written by exactly one of the two threads (0, t), (1, t))
+        __syncthreads();
+        if (mine_to_finish) {
+            const float4 got = x[t];
+            if (first) grad_finish_w<SO>(a, m0, n0, 0, mine.sum[0], got, w_old);
+            else grad_finish_w<SO>(a, m0, n0, 0, got, mine.sum[0], w_old);
+        }
+    }
 }
 
 // PAR (both data operands uint8: the Gibbs states of the CD-k / PCD step): 512 threads, the phases side by side.
 // Otherwise (fp32 data: twice the staging bytes, two regions do not fit the LDS): 256 threads, phase after phase.
 // ONE (the discriminative step): phase 0 only -- gW = A0^T.P0 -- and the kind D workgroups behind the strips; 256 threads.
-template <class T0, class T1, bool FAST, bool PAR, bool ONE = false>
+template <class T0, class T1, bool FAST, bool PAR, bool ONE, int NT>
 __global__ __launch_bounds__(PAR ? 512 : 256) void k_grad(GradArgs a)
 {
     static_assert(!(PAR && ONE), "the one-phase form takes the 256-thread kernel");
-    constexpr int MT = G_MT, NT = G_NT;
+    constexpr int MT = G_MT;
     extern __shared__ __attribute__((aligned(16))) char lds_all[];
     QBM_STAMP(10);
     asm volatile("" ::"s"(a.A0), "s"(a.P0), "s"(a.A1), "s"(a.P1), "s"(a.gW), "s"(a.W), "s"(a.B), "s"(a.V), "s"(a.H), "s"(a.C),
@@ -1860,13 +1884,13 @@ struct DiscExtras {
     float* dgU; float* dgc; float* duU; float* duc; float* dub;
 };
 
-template <class T0, class T1, bool PAR>
+template <class T0, class T1, bool PAR, int NT>
 int launch_grad_t(int V, int H, int C, int B, const void* A0, const float* Y0, const float* P0, const void* A1,
                   const float* Y1, const float* P1, const qbm_rbm_grads* G, float* W_fused, const qbm_rbm_params* aux_fused,
                   float lr, float factor, float bs, float sparse, hipStream_t st, const float* gU_sub, const uint32_t* status,
                   const DiscExtras* dx, const float* mon_rowloss, double* mon_loss_acc)
 {
-    constexpr int MT = G_MT, NT = G_NT;
+    constexpr int MT = G_MT;
     const int nM = (V + 16 * MT - 1) / (16 * MT), nN = (H + 16 * NT - 1) / (16 * NT);
     const bool want_b = G->gb || (aux_fused && aux_fused->b);
     const bool want_c = G->gc || (aux_fused && aux_fused->c);
@@ -1879,23 +1903,11 @@ int launch_grad_t(int V, int H, int C, int B, const void* A0, const float* Y0, c
                0, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (mon_rowloss && mon_loss_acc) { a.nL = 1; a.rowloss = mon_rowloss; a.loss_acc = mon_loss_acc; }
     if (dx) {
-        const int nJ = (H + 15) / 16;
-        // one workgroup per CU (an fp32 operand: 96 KB of staging): as many kind D workgroups as CUs the strips leave free, if
-        // 2 or 4 column blocks per workgroup get there (C = 2 at H = 512: 16 workgroups of 4 blocks beside 238 others: 25.1 us
-        // per step instead of 26.5; 8 blocks -- C = 4 -- take longer than the strips beside them: 35 us instead of 28)
-        const bool one_per_cu = !(sizeof(T0) == 1 && sizeof(T1) == 1);
-        const int others = a.nU + a.nB + a.nC + nM * nN;
-        a.dW = 1;
-        if (one_per_cu && others < 256 && C * nJ > 256 - others)
-            for (int w = 2; w <= 4; w *= 2)
-                if (C * ((nJ + w - 1) / w) <= 256 - others) { a.dW = w; break; }
-        a.nD = C * ((nJ + a.dW - 1) / a.dW);
         a.pre = dx->pre; a.Up = dx->U; a.pyx = dx->pyx; a.labels = dx->labels; a.rowloss = dx->rowloss; a.loss_acc = dx->loss_acc;
         a.dgU = dx->dgU; a.dgc = dx->dgc; a.duU = dx->duU; a.duc = dx->duc; a.dub = dx->dub;
     }
     const bool fast = (B % 16 == 0) && (V % 16 == 0) && (H % 4 == 0) && aligned16(A0) && (!P1 || aligned16(A1)) && aligned16(P0) &&
                       aligned16(P1) && small2g((long)B * V, 4) && small2g((long)B * H, 4);
-    const int grid = a.nU + a.nB + a.nC + nM * nN + a.nD + a.nL;
     // PAR: the phases side by side (both operands uint8, two phases); otherwise 256 threads, phase after phase -- or one
     // phase only (P1 == null: the discriminative step)
     static_assert(!PAR || (sizeof(T0) == 1 && sizeof(T1) == 1), "the phase-parallel kernel takes uint8 data");
@@ -1920,10 +1932,24 @@ int launch_grad_t(int V, int H, int C, int B, const void* A0, const float* Y0, c
         if (lds < (size_t)strip_lds_bytes<1, NT, 4>(a.KP)) lds = strip_lds_bytes<1, NT, 4>(a.KP);   // kinds U, C: synthesised fp32 tile
         if (lds < 24576) lds = 24576;                                                                // kind D / kind L: their LDS arrays
     }
+    if (dx) {
+        // Kind D workgroups (class c, 16 hidden columns) stand behind the strips.  Where the launch's LDS allows ONE workgroup per
+        // CU only, 2 or 4 column blocks per kind D workgroup are taken if that lets them run beside the strips instead of
+        // queueing for further rounds (8 blocks take longer than a strip; with two workgroups per CU the queue is cheaper than
+        // the wider workgroups: C = 4, fp32: 24.1 us per step with one block each, 27.0 with two -- measured)
+        const int nJ = (H + 15) / 16;
+        const int slots = 256 * (int)(163840 / lds), others = a.nU + a.nB + a.nC + nM * nN;
+        a.dW = 1;
+        if (slots == 256 && others < slots && C * nJ > slots - others)
+            for (int w = 2; w <= 4; w *= 2)
+                if (C * ((nJ + w - 1) / w) <= slots - others) { a.dW = w; break; }
+        a.nD = C * ((nJ + a.dW - 1) / a.dW);
+    }
+    const int grid = a.nU + a.nB + a.nC + nM * nN + a.nD + a.nL;
 #define QBM_LAUNCH(F, ONE)                                                                                     \
     {                                                                                                           \
-        if (int rc = set_lds(k_grad<T0, T1, F, PAR, ONE>, lds)) return rc;                                      \
-        hipLaunchKernelGGL((k_grad<T0, T1, F, PAR, ONE>), dim3(grid), dim3(PAR ? 512 : 256), lds, st, a);       \
+        if (int rc = set_lds(k_grad<T0, T1, F, PAR, ONE, NT>, lds)) return rc;                                  \
+        hipLaunchKernelGGL((k_grad<T0, T1, F, PAR, ONE, NT>), dim3(grid), dim3(PAR ? 512 : 256), lds, st, a);   \
     }
     if constexpr (PAR) {
         if (fast) QBM_LAUNCH(true, false) else QBM_LAUNCH(false, false)
@@ -1949,10 +1975,16 @@ int launch_grad(int V, int H, int C, int B, const void* A0, int d0, const float*
                 double* mon_loss_acc = nullptr)
 {
     if (C + 1 > 16) return fail(QBM_ERR_ARG, "two_phase_grad: at most 15 classes (class rows + the bias row share one 16-row tile)");
-#define QBM_G(T0, T1, PAR) launch_grad_t<T0, T1, PAR>(V, H, C, B, A0, Y0, P0, A1, Y1, P1, G, W_fused, aux_fused, lr, factor, bs, sparse, st, gU_sub, status, dx, mon_rowloss, mon_loss_acc)
-    if (d0 == QBM_U8 && d1 == QBM_U8) return (P1 && !dx) ? QBM_G(uint8_t, uint8_t, true) : QBM_G(uint8_t, uint8_t, false);
-    if (d0 == QBM_U8) return QBM_G(uint8_t, float, false);
-    return d1 == QBM_U8 ? QBM_G(float, uint8_t, false) : QBM_G(float, float, false);
+#define QBM_G(T0, T1, PAR, NT) launch_grad_t<T0, T1, PAR, NT>(V, H, C, B, A0, Y0, P0, A1, Y1, P1, G, W_fused, aux_fused, lr, factor, bs, sparse, st, gU_sub, status, dx, mon_rowloss, mon_loss_acc)
+    // strips of 64 x 16 for the one-phase form and where 64 x 32 strips would leave half of the CUs idle (see G_MT)
+    const bool narrow = dx || !P1 || ((V + 16 * G_MT - 1) / (16 * G_MT)) * ((H + 31) / 32) < 128;
+    if (d0 == QBM_U8 && d1 == QBM_U8) {
+        if (P1 && !dx) return narrow ? QBM_G(uint8_t, uint8_t, true, 1) : QBM_G(uint8_t, uint8_t, true, 2);
+        return QBM_G(uint8_t, uint8_t, false, 1);
+    }
+    if (d0 == QBM_U8) return QBM_G(uint8_t, float, false, 2);
+    if (d1 == QBM_U8) return QBM_G(float, uint8_t, false, 2);
+    return (dx || !P1) ? QBM_G(float, float, false, 1) : QBM_G(float, float, false, 2);
 #undef QBM_G
 }
 
