@@ -5,7 +5,7 @@ other buffers: ~6-8 us, no dynamic LDS, so it can share CUs with every strip ker
 (b) forked off behind the first launch and joined in front of the last.  One JSON line: us per step of the plain step, of (a)
 and of (b).  (b) - plain = what the fork / join itself costs when the overlap is perfect; (a) - (b) = what overlap buys."""
 import ctypes as C, json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from qbm_image_classification_amd._lib import QBM_U8, check, ptr

@@ -1,6 +1,6 @@
 """CD-1 step time (hipGraph of 8 steps, 200 replays) with the fused tail (k_hgrad) and with one launch per phase."""
 import sys, os, json
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from qbm_image_classification_amd.rbm_ops import GradSet, HipRbmOps, ParamSet
