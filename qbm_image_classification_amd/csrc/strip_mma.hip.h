@@ -225,16 +225,12 @@ struct ViewCContigU8 {
         return DmaLane{c0 < cols ? (unsigned)(k * (int)ld + c0) : kOOB, (unsigned)(64 * ld), k, 64};
     }
     // transfer instruction j (0..TILES-1) of a quad, all TILES adjacent 16-wide tiles from column c0 on: lane L takes
-    // k = kb + (64/TILES)*j + L/TILES of tile L % TILES.  TILES == 8: a k row is 128 bytes, so the rows k and k + 1 that
-    // the lane groups g and g + 1 of a ds_read_u8 read (one 32-lane banking group) would meet on the same banks; odd k
-    // rows are therefore stored with their tiles 0-3 and 4-7 swapped (slot tile ^ 4): a per-lane SOURCE address here, a
-    // per-lane constant in the fragment address (strip_mma: fragA / adA) -- conflict-free like the 4-tile image.
+    // k = kb + (64/TILES)*j + L/TILES of tile L % TILES
     template <int TILES>
     __device__ __forceinline__ DmaLane lane0_tiles(int c0, int kb, int lane, int j) const
     {
-        const int kl = lane / TILES;
-        const int tile = TILES == 8 ? ((lane % TILES) ^ ((kl & 1) << 2)) : lane % TILES;
-        const int k = kb + (64 / TILES) * j + kl, c = c0 + 16 * tile;
+        static_assert(TILES == 1 || TILES == 2 || TILES == 4, "a k row of TILES * 16 bytes: at 8 tiles the rows k and k + 1 that one ds_read_u8 reads would meet on the same banks");
+        const int k = kb + (64 / TILES) * j + lane / TILES, c = c0 + 16 * (lane % TILES);
         return DmaLane{c < cols ? (unsigned)(k * (int)ld + c) : kOOB, (unsigned)(64 * ld), k, 64};
     }
     __device__ __forceinline__ uint4 get(int c0, int kb, int kend, int slot) const
@@ -588,11 +584,7 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
         using std::integral_constant;
         uint32_t adA[MT], adB[NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            // (8-tile u8 lin image: odd k rows hold their tiles 0-3 / 4-7 swapped, and k = 4s + g is odd with g: lane0_tiles)
-            const int ti = (A_TILES && MT == 8) ? (i ^ (((lane >> 4) & 1) << 2)) : i;
-            adA[i] = lds_off(imgA) + (uint32_t)(fragA + ti * a_tile + qd * 4 * kPieceA);
-        }
+        for (int i = 0; i < MT; ++i) adA[i] = lds_off(imgA) + (uint32_t)(fragA + i * a_tile + qd * 4 * kPieceA);
 #pragma unroll
         for (int t = 0; t < NT; ++t) adB[t] = lds_off(imgB) + (uint32_t)(fragB + t * b_tile + qd * 4096);
         auto reads1 = [&](auto PC, Frag& f) {   // chunk 1: at most 15 reads
@@ -773,8 +765,7 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
 #pragma unroll
                     for (int i = 0; i < MT; ++i) {
                         const uint4 v = view_get<KPERM>(A, m0 + 16 * i, kb, kend, g * 64 + lane);
-                        if constexpr (A_TILES)   // slot k*MT + tile (8 tiles: odd k rows swap their halves, see lane0_tiles)
-                            reinterpret_cast<uint4*>(imgA)[(g * 64 + lane) * MT + (MT == 8 ? (i ^ ((lane & 1) << 2)) : i)] = v;
+                        if constexpr (A_TILES) reinterpret_cast<uint4*>(imgA)[(g * 64 + lane) * MT + i] = v;   // slot k*MT + tile
                         else reinterpret_cast<uint4*>(imgA + i * a_tile)[g * 64 + lane] = v;
                     }
             } else {
