@@ -14,6 +14,8 @@ to probabilities (Q1, :142); roc_auc_score is computed on hard predictions (Q4, 
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -78,6 +80,8 @@ class ClassificationRBM:
         self._chain_y = None
         self._rank_rows = None    # nominal minibatch rows per rank (set by train_rbm from the loader's batch_size)
         self._pset = None
+        self._loss_sums = None    # float64 [2] on the device: the running loss sums of train_rbm's current epoch
+        self._epoch_graph = None  # (key, hipGraph of one discriminative epoch from a device-resident dataset)
         if self.data_parallel and hasattr(self.ops, "status_agree"):
             self.ops.status_agree = self._agree_chain_status
 
@@ -284,7 +288,18 @@ class ClassificationRBM:
         # a DeviceDataset hands out device tensors as the kernels take them (uint8 / fp32 rows, int32 labels, one-hot rows
         # from the same gather launch): no conversion launches per step
         resident = hasattr(train_loader, 'batches') and hasattr(train_loader, 'epoch')
-        sums = torch.zeros(2, dtype=torch.float64, device=self.device)
+        if self._loss_sums is None:   # (one pair for the life of the object: a captured epoch graph holds its address)
+            self._loss_sums = torch.zeros(2, dtype=torch.float64, device=self.device)
+        sums = self._loss_sums
+        # Discriminative epochs from a device-resident dataset are captured in ONE hipGraph and replayed: the launches of an
+        # epoch have the same arguments in every epoch (the dataset keeps its epoch buffers, the rule draws no random numbers,
+        # the loss sums are device memory), so from the second epoch on an epoch costs the host one gather and one replay --
+        # the loop then runs at the kernels' speed whatever the host's (eager launches sit at the edge of being host-bound:
+        # ~25 us of Python + launch calls per 25 us step).  Same launches, same order: same bits.
+        graph_ok = (resident and method == 'discriminative' and not self.data_parallel and self.device.type == 'cuda'
+                    and getattr(train_loader, 'epoch_gather', False) and hasattr(self.ops, 'lib')
+                    and os.environ.get('QBM_EPOCH_GRAPH', '1') != '0')
+        epoch_graph = self._epoch_graph   # (kept across calls: a later train_rbm on the same data replays from its first epoch)
         for epoch in range(epochs):
             # The two running sums of the epoch (:187 `epoch_error += batch_error.item()`, :191 `epoch_nll += nll.item()`)
             # live ON THE DEVICE as float64: the gradient launch of every step adds its minibatch's terms (per row
@@ -295,6 +310,22 @@ class ClassificationRBM:
                 batches = train_loader.batches(want_onehot=method != 'discriminative')
             else:
                 batches = ((b, l, None) for b, l in train_loader)
+            if graph_ok and (epoch >= 1 or epoch_graph is not None):
+                # (The first epoch of a fresh object runs eagerly: every workspace exists afterwards.)  The generator's first
+                # step performs the epoch's gather into the dataset's buffers; the minibatches it yields are the same views in
+                # every epoch.
+                views = list(batches)
+                key = (id(getattr(train_loader, 'last_views', None)), len(views), views[0][0].data_ptr() if views else 0) + (
+                    id(self._params()), float(self.learning_rate), float(self.sparse_constant), float(discriminative_factor), self.keep_grads)
+                if epoch_graph is None or epoch_graph[0] != key:
+                    g = torch.cuda.CUDAGraph()
+                    torch.cuda.synchronize()
+                    with torch.cuda.graph(g):
+                        for batch, labels, _ in views:
+                            self._disc_step(batch, labels, discriminative_factor, sums, False)
+                    epoch_graph = self._epoch_graph = (key, g)
+                epoch_graph[1].replay()
+                batches = ()
             for batch, labels, onehot in batches:
                 if not resident:
                     batch = batch.view(len(batch), self.num_visible)  # flatten input data (:173)

@@ -56,12 +56,17 @@ class HipDataOps:
         """Epoch permutation: stable ascending argsort of the Philox keys (int32 indices)."""
         return torch.argsort(self.shuffle_keys(seed, epoch, n), stable=True).to(torch.int32)
 
-    def gather(self, src, src_kind, idx, num_visible, dst_kind=QBM_F32, labels=None, num_classes=0, want_onehot=False):
+    def gather(self, src, src_kind, idx, num_visible, dst_kind=QBM_F32, labels=None, num_classes=0, want_onehot=False, out=None):
+        """out: (dst, lab, one) buffers of the right shapes to write into (an epoch's buffers, kept by the dataset so that their
+        addresses do not change from epoch to epoch), or None = fresh tensors."""
         idx = idx.to(self.device, torch.int32).contiguous()
         b = idx.numel()
-        dst = torch.empty(b, num_visible, dtype=torch.float32 if dst_kind == QBM_F32 else torch.uint8, device=self.device)
-        lab = torch.empty(b, dtype=torch.int32, device=self.device) if labels is not None else None
-        one = torch.empty(b, num_classes, dtype=torch.float32, device=self.device) if (labels is not None and want_onehot) else None
+        if out is not None:
+            dst, lab, one = out
+        else:
+            dst = torch.empty(b, num_visible, dtype=torch.float32 if dst_kind == QBM_F32 else torch.uint8, device=self.device)
+            lab = torch.empty(b, dtype=torch.int32, device=self.device) if labels is not None else None
+            one = torch.empty(b, num_classes, dtype=torch.float32, device=self.device) if (labels is not None and want_onehot) else None
         check(self.lib.qbm_data_gather(ptr(src), src_kind, ptr(idx), b, num_visible, ptr(dst), dst_kind, ptr(labels), ptr(lab),
                                        ptr(one), int(num_classes), current_stream()), "qbm_data_gather")
         return dst, lab, one
@@ -96,6 +101,7 @@ class DeviceDataset:
         self.rank, self.world = int(rank), int(world)
         self.epoch_gather = bool(epoch_gather)
         self.epoch = 0
+        self._epoch_bufs = {}
         self.labels = torch.as_tensor(np.asarray(y) if not torch.is_tensor(y) else y).reshape(-1).to(dev, torch.int32).contiguous()
         if self.labels.numel() != self.N:
             raise ValueError("x and y disagree on the number of samples")
@@ -137,15 +143,33 @@ class DeviceDataset:
             if self.world > 1:
                 pos = torch.arange(mine.numel(), device=mine.device) % g
                 mine = mine[(pos >= self.rank * self.batch_size) & (pos < (self.rank + 1) * self.batch_size)]
-            X, L, O = (self.ops.gather(self.data, self.kind, mine, self.V, self.out_kind, self.labels, self.num_classes, want_onehot)
+            # the epoch's buffers are kept: a minibatch is the SAME slice of the same storage in every epoch (a training loop may
+            # capture an epoch's launches in a hipGraph once and replay it: ClassificationRBM.train_rbm)
+            nb = int(mine.numel())
+            key = (nb, bool(want_onehot))
+            if nb and self._epoch_bufs.get("key") != key:
+                dt = torch.float32 if self.out_kind == QBM_F32 else torch.uint8
+                dev = self.ops.device
+                self._epoch_bufs = {"key": key, "bufs": (torch.empty(nb, self.V, dtype=dt, device=dev), torch.empty(nb, dtype=torch.int32, device=dev),
+                                                        torch.empty(nb, self.num_classes, dtype=torch.float32, device=dev) if want_onehot else None)}
+            X, L, O = (self.ops.gather(self.data, self.kind, mine, self.V, self.out_kind, self.labels, self.num_classes, want_onehot,
+                                       out=self._epoch_bufs["bufs"])
                        if mine.numel() else (torch.empty(0, self.V, dtype=torch.float32 if self.out_kind == QBM_F32 else torch.uint8,
                                                          device=self.ops.device), torch.empty(0, dtype=torch.int32, device=self.ops.device), None))
-            at = 0
-            for k in range(len(self)):
-                lo = k * g + self.rank * self.batch_size
-                n = max(0, min(lo + self.batch_size, min((k + 1) * g, self.N)) - lo)
-                yield X[at:at + n], L[at:at + n], (O[at:at + n] if O is not None else None)
-                at += n
+            # the minibatch views of the epoch buffers are made once (a torch slice costs ~2 us: three per step would be a fifth
+            # of a training step) and handed out again in every epoch: the same objects, the same storage, new contents
+            views = self._epoch_bufs.get("views") if nb else None
+            if views is None:
+                views, at = [], 0
+                for k in range(len(self)):
+                    lo = k * g + self.rank * self.batch_size
+                    n = max(0, min(lo + self.batch_size, min((k + 1) * g, self.N)) - lo)
+                    views.append((X[at:at + n], L[at:at + n], (O[at:at + n] if O is not None else None)))
+                    at += n
+                if nb:
+                    self._epoch_bufs["views"] = views
+            self.last_views = views   # (identity = "the same launches as last epoch" for a loop that captures them)
+            yield from views
             return
         for k in range(len(self)):
             lo = k * g + self.rank * self.batch_size

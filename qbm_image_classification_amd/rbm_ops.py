@@ -91,7 +91,8 @@ class HipRbmOps:
         if not torch.cuda.is_available():
             raise _lib.QbmHipError("no ROCm device visible: the HIP path cannot run (there is no CPU fallback)")
         self.device = torch.device(device)
-        self._disc_ws = None
+        self._disc_ws = None     # the discriminative step's scratch of the last call; _disc_wss: one per minibatch shape
+        self._disc_wss = {}
         self._cd_ws = None       # (key, workspace) of the last cd_step that used a cached workspace
         self._cd_wss = {}        # minibatch shape -> workspace (they share the one sync buffer)
         self._sync = None        # state of the fused chain kernel (round flags, status word)
@@ -203,9 +204,14 @@ class HipRbmOps:
         B = x.shape[0]
         key = (B, P.H, P.C, 0 if loss_acc is None else loss_acc.data_ptr())
         if self._disc_ws is None or self._disc_ws[0] != key:   # scratch reused from step to step (stream-ordered)
-            f = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.device)
-            bufs = (f(B, P.H), f(B, P.H), f(B, 2), f(B, P.C))
-            self._disc_ws = (key, bufs, DiscWorkspace(ptr(bufs[0]), ptr(bufs[1]), ptr(bufs[2]), ptr(loss_acc)), loss_acc)
+            hit = self._disc_wss.get(key)   # (one per minibatch shape: the full minibatch and a short last one alternate)
+            if hit is None:
+                if len(self._disc_wss) >= self.kWorkspaces:
+                    self._disc_wss.pop(next(iter(self._disc_wss)))
+                f = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.device)
+                bufs = (f(B, P.H), f(B, P.H), f(B, 2), f(B, P.C))
+                hit = self._disc_wss[key] = (key, bufs, DiscWorkspace(ptr(bufs[0]), ptr(bufs[1]), ptr(bufs[2]), ptr(loss_acc)), loss_acc)
+            self._disc_ws = hit
         ws = self._disc_ws[2]
         if p_out is None:
             p_out = torch.empty(B, P.C, dtype=torch.float32, device=self.device)

@@ -208,12 +208,19 @@ class OracleDataOps:
 
         return torch.from_numpy(orc.data_shuffle_perm(seed, epoch, n).astype(np.int32))
 
-    def gather(self, src, src_kind, idx, num_visible, dst_kind=0, labels=None, num_classes=0, want_onehot=False):
+    def gather(self, src, src_kind, idx, num_visible, dst_kind=0, labels=None, num_classes=0, want_onehot=False, out=None):
         import torch
 
-        out = orc.data_gather(src.numpy(), idx.numpy(), None if labels is None else labels.numpy(), num_classes,
+        res = orc.data_gather(src.numpy(), idx.numpy(), None if labels is None else labels.numpy(), num_classes,
                               num_visible if src_kind == 2 else None, np.float32 if dst_kind == 0 else np.uint8)
         if labels is None:
-            return torch.from_numpy(out), None, None
-        rows, lab, one = out
-        return torch.from_numpy(rows), torch.from_numpy(lab), torch.from_numpy(one) if want_onehot else None
+            got = (torch.from_numpy(res), None, None)
+        else:
+            rows, lab, one = res
+            got = (torch.from_numpy(rows), torch.from_numpy(lab), torch.from_numpy(one) if want_onehot else None)
+        if out is None:
+            return got
+        for dst, src_t in zip(out, got):   # the dataset's epoch buffers (same storage in every epoch)
+            if dst is not None:
+                dst.copy_(src_t)
+        return out

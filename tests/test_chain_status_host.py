@@ -36,7 +36,7 @@ def ops(monkeypatch):
     monkeypatch.setattr(rbm_ops, "current_stream", lambda: None)
     o = object.__new__(rbm_ops.HipRbmOps)
     o.lib, o.device = _StubLib(), torch.device("cpu")
-    o._disc_ws, o._cd_ws, o._cd_wss, o._sync, o._pending, o.status_agree = None, None, {}, None, [], None
+    o._disc_ws, o._disc_wss, o._cd_ws, o._cd_wss, o._sync, o._pending, o.status_agree = None, {}, None, {}, None, [], None
     return o
 
 
