@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QBM_ABI_VERSION 12
+#define QBM_ABI_VERSION 13
 #define QBM_MAX_CLASSES 15 /* class rows + the bias row share one 16-row gradient tile */
 #define QBM_MAX_QUBO_VARS 1024
 
@@ -191,6 +191,12 @@ typedef struct {
     float* mon_p;              /* [B,C] p(y|x0) */
     float* mon_rowloss;        /* [B,2] */
     double* mon_loss_acc;      /* [2] */
+    /* Optional device-side draw counters, [2] uint64: every sampling launch of qbm_rbm_cd_chain / qbm_rbm_cd_step adds word 0 to
+     * its draw ids (`offset` ...) and word 1 (mod 2^32) to `row0`.  A training loop that captures an epoch's steps in a
+     * hipGraph passes offsets RELATIVE to the epoch in the arguments and moves these two words between replays: the captured
+     * launches keep their arguments, the draws advance exactly as with host-side counters.  With the words set the step takes
+     * one launch per phase (the one-launch kernels record a step's draw offset for their fail-safe from the arguments). */
+    const uint64_t* draw_base;
 } qbm_rbm_cd_workspace;
 #define QBM_CD_SYNC_WORDS 3136
 

@@ -8,7 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libqbm_hip.so")
 
-QBM_ABI_VERSION = 12
+QBM_ABI_VERSION = 13
 QBM_MAX_CLASSES = 15
 QBM_F32, QBM_U8 = 0, 1
 
@@ -32,7 +32,8 @@ class CdWorkspace(C.Structure):
                 ("sync", C.c_void_p),   # state of the fused chain kernel (QBM_CD_SYNC_WORDS uint32, zeroed once) or None
                 # the training loop's monitor (include/qbm_hip.h): labels, x.W + d, p(y|x), per-row loss terms, running sums
                 ("mon_labels", C.c_void_p), ("mon_pre", C.c_void_p), ("mon_p", C.c_void_p), ("mon_rowloss", C.c_void_p),
-                ("mon_loss_acc", C.c_void_p)]
+                ("mon_loss_acc", C.c_void_p),
+                ("draw_base", C.c_void_p)]   # optional [2] uint64 device words added to (offset, row0) by every sampling launch
 
 
 QBM_CD_SYNC_WORDS = 3136

@@ -81,7 +81,8 @@ class ClassificationRBM:
         self._rank_rows = None    # nominal minibatch rows per rank (set by train_rbm from the loader's batch_size)
         self._pset = None
         self._loss_sums = None    # float64 [2] on the device: the running loss sums of train_rbm's current epoch
-        self._epoch_graph = None  # (key, hipGraph of one discriminative epoch from a device-resident dataset)
+        self._epoch_graph = None  # (key, hipGraph of one epoch from a device-resident dataset)
+        self._draw_base = None    # int64 [2] on the device: base of the draw ids / Philox rows of a captured generative epoch
         if self.data_parallel and hasattr(self.ops, "status_agree"):
             self.ops.status_agree = self._agree_chain_status
 
@@ -207,13 +208,15 @@ class ClassificationRBM:
         _, predicted = torch.max(p, 1)
         return error, predicted, p
 
-    def contrastive_divergence_training(self, input_data, class_label, factor=1, *, onehot=None, loss_acc=None):
+    def contrastive_divergence_training(self, input_data, class_label, factor=1, *, onehot=None, loss_acc=None, _rel=None):
         """CD-k (or PCD when persistent=True) generative step, SURVEY.md 8.A-7:
         dW = v0^T p(h0) - vk^T p(hk), db = sum(v0 - vk), dd = sum(p(h0) - p(hk)), dU = y0^T p(h0) - yk^T p(hk),
         dc = sum(y0 - yk); update rule of src/ClassificationRBM.py:88-99.
         onehot: the labels as fp32 one-hot rows if the caller has them (DeviceDataset delivers them with the gather);
         loss_acc: float64 [2] device tensor -- the step then also evaluates p(y|x) of its minibatch under the parameters
-        BEFORE its update (what discriminative_training reports) and adds the two loss terms of train_rbm's bookkeeping."""
+        BEFORE its update (what discriminative_training reports) and adds the two loss terms of train_rbm's bookkeeping.
+        _rel (train_rbm's captured epochs): (step index in the epoch, [2] device words) -- draw ids and Philox rows are passed
+        RELATIVE to the epoch and the device words supply the epoch's base; the host counters are advanced by the caller."""
         batch_size = input_data.size(0)
         P = self._params()
         if onehot is None:
@@ -230,8 +233,15 @@ class ClassificationRBM:
         # uint8 {0,1} minibatches (DeviceDataset with binary storage) stay bytes: the Gibbs kernels read them as such
         v0 = v0.to(self.device) if v0.dtype == torch.uint8 else v0.to(self.device, torch.float32)
         lr, sp = float(self.learning_rate), float(self.sparse_constant)
-        row0 = (self._rows_seen + self._rank_row_offset(batch_size)) & 0xFFFFFFFF
-        offset = self._next_offset(3 * self.k + 1)
+        nominal = int(self._rank_rows if self._rank_rows else batch_size)
+        if _rel is None:
+            row0 = (self._rows_seen + self._rank_row_offset(batch_size)) & 0xFFFFFFFF
+            offset = self._next_offset(3 * self.k + 1)
+            draw_base = None
+        else:
+            row0 = (_rel[0] * nominal * self._world() + self._rank_row_offset(batch_size)) & 0xFFFFFFFF
+            offset = _rel[0] * (3 * self.k + 1)
+            draw_base = _rel[1]
         if self.persistent and (self._chain_v is None or self._chain_v.shape[0] < batch_size):
             # chains start at the data.  Chain states are binary (uint8): {0,1} data are taken as they are,
             # greyscale data are thresholded at 0.5 (data_loader.binarise's rule)
@@ -257,12 +267,13 @@ class ClassificationRBM:
                 self.ops.update(P, G, lr, f, bs, sp, guard_chain=True)
         else:  # every update fused into the gradient launch
             def step():
-                self.ops.cd_step(P, G, v0, y0, k, seed, offset, row0, cv, cy, True, lr, f, bs, sp, replay=step, monitor=monitor)
+                self.ops.cd_step(P, G, v0, y0, k, seed, offset, row0, cv, cy, True, lr, f, bs, sp, replay=step, monitor=monitor,
+                                 draw_base=draw_base)
         step()
         # Philox rows advance by the NOMINAL global minibatch (the loader's batch_size x ranks; a short last minibatch
         # included): known on the host of every rank without asking the device for the all-reduced row count
-        nominal = int(self._rank_rows if self._rank_rows else batch_size)
-        self._rows_seen += nominal * self._world()
+        if _rel is None:
+            self._rows_seen += nominal * self._world()
         return None
 
     def _sigmoid(self, x):
@@ -296,9 +307,16 @@ class ClassificationRBM:
         # the loss sums are device memory), so from the second epoch on an epoch costs the host one gather and one replay --
         # the loop then runs at the kernels' speed whatever the host's (eager launches sit at the edge of being host-bound:
         # ~25 us of Python + launch calls per 25 us step).  Same launches, same order: same bits.
-        graph_ok = (resident and method == 'discriminative' and not self.data_parallel and self.device.type == 'cuda'
+        graph_ok = (resident and method in ('discriminative', 'generative') and not self.data_parallel and self.device.type == 'cuda'
                     and getattr(train_loader, 'epoch_gather', False) and hasattr(self.ops, 'lib')
                     and os.environ.get('QBM_EPOCH_GRAPH', '1') != '0')
+        # The generative rules draw random numbers: their captured launches carry draw ids and Philox rows RELATIVE to the epoch,
+        # and two device words (qbm_rbm_cd_workspace.draw_base) carry the epoch's base -- moved between replays, so the draws
+        # are those of the eager loop.  Only where the step is one launch per phase (CD-1 by default: the one-launch chain keeps
+        # its fail-safe record on the host, per step) and the update rides in the gradient launch.
+        if graph_ok and method == 'generative':
+            from ._lib import QBM_U8
+            graph_ok = not self.keep_grads and not self.ops._may_fuse(self.k, QBM_U8)
         epoch_graph = self._epoch_graph   # (kept across calls: a later train_rbm on the same data replays from its first epoch)
         for epoch in range(epochs):
             # The two running sums of the epoch (:187 `epoch_error += batch_error.item()`, :191 `epoch_nll += nll.item()`)
@@ -316,14 +334,25 @@ class ClassificationRBM:
                 # every epoch.
                 views = list(batches)
                 key = (id(getattr(train_loader, 'last_views', None)), len(views), views[0][0].data_ptr() if views else 0) + (
-                    id(self._params()), float(self.learning_rate), float(self.sparse_constant), float(discriminative_factor), self.keep_grads)
+                    id(self._params()), float(self.learning_rate), float(self.sparse_constant), float(discriminative_factor), self.keep_grads,
+                    method, float(gen_factor), self.k, self.persistent)
                 if epoch_graph is None or epoch_graph[0] != key:
+                    if self._draw_base is None:
+                        self._draw_base = torch.zeros(2, dtype=torch.int64, device=self.device)
                     g = torch.cuda.CUDAGraph()
                     torch.cuda.synchronize()
                     with torch.cuda.graph(g):
-                        for batch, labels, _ in views:
-                            self._disc_step(batch, labels, discriminative_factor, sums, False)
+                        for i, (batch, labels, onehot) in enumerate(views):
+                            if method == 'discriminative':
+                                self._disc_step(batch, labels, discriminative_factor, sums, False)
+                            else:
+                                self.contrastive_divergence_training(batch, labels, gen_factor, onehot=onehot, loss_acc=sums,
+                                                                     _rel=(i, self._draw_base))
                     epoch_graph = self._epoch_graph = (key, g)
+                if method == 'generative':   # this epoch's base of the draw ids / Philox rows, then the host counters move on
+                    self._draw_base.copy_(torch.tensor([self._draw_offset, self._rows_seen & 0xFFFFFFFF], dtype=torch.int64))
+                    self._draw_offset += len(views) * (3 * self.k + 1)
+                    self._rows_seen += len(views) * int(self._rank_rows if self._rank_rows else views[0][0].shape[0]) * self._world()
                 epoch_graph[1].replay()
                 batches = ()
             for batch, labels, onehot in batches:

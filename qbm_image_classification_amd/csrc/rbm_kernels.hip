@@ -58,6 +58,9 @@ constexpr int G_MT = 4;
         else { MACRO(QBM_MAX_CLASSES); }            \
     } while (0)
 
+// Device-side draw counters (HiddenArgs / VisibleArgs::draw_base) are a COMPILE-TIME variant of the sampling kernels (DB): read
+// at run time behind a null test they cost k_visible 0.7 us per launch, read unconditionally from a zero pair still 0.2 us --
+// the default path carries none of it.
 template <class T> struct KView;   // K-contiguous A operand of element type T
 template <> struct KView<float> { using type = ViewKContig; };
 template <> struct KView<uint8_t> { using type = ViewKContigU8; };
@@ -98,6 +101,8 @@ struct HiddenArgs {
     const uint32_t* status;   // non-null: status word of the step's workspace (sync[512]); non-zero = an earlier fused
                               // launch on it gave up and the host has not looked yet: this launch stores nothing (the
                               // workspace keeps what the host needs to finish that step: k_hgrad)
+    const uint64_t* draw_base;   // non-null: [2] device words added to (offset, row0) -- qbm_rbm_cd_workspace.draw_base: the
+                                 // launches of an epoch captured in a hipGraph keep their arguments, the counters move on
 };
 
 // 8 wavefronts (512 threads): wavefront q contracts chain q of the 8 the K = V terms are cut into ([Q] with NQ = 8), two
@@ -109,7 +114,7 @@ constexpr int H_NQ = 8;
 // AUX: cache policy of the loads of v and y (kSc1 inside the fused chain kernel: another workgroup of the XCD wrote them
 // during this launch; FASTK == 2 only).  The body of strip (ms, ns); the caller is a 512-thread workgroup.
 // post: strip_mma's hook between the contraction and the combine (k_hgrad requests the gradient's operands there)
-template <class TA, int FASTK, int MODE, int CM, int AUX = 0, class Post = NoPre>
+template <class TA, int FASTK, int MODE, int CM, int AUX = 0, class Post = NoPre, bool DB = false>
 __device__ __forceinline__ void hidden_body(const HiddenArgs& a, int ms, int ns, char* lds, char* ldsB = nullptr,
                                             bool b_resident = false, Post&& post = NoPre{})
 {
@@ -126,6 +131,9 @@ __device__ __forceinline__ void hidden_body(const HiddenArgs& a, int ms, int ns,
     const int i_c = min(row, a.B - 1), j_c = min(j0, a.H - 1);
     const bool with_cls = MODE == 0 && a.y != nullptr;
     const uint32_t st_w = a.status ? *a.status : 0u;   // a scalar load issued here, consumed in front of the stores
+    uint64_t off_b = 0ull;   // (DB: loaded here, consumed in `pre`, behind the first transfers)
+    uint32_t row_b = 0u;
+    if constexpr (DB) { off_b = a.draw_base[0]; row_b = (uint32_t)a.draw_base[1]; }
     // Everything of the epilogue that does not depend on the contraction -- bias and class-term operands, the class chain
     // (classes c >= C enter it as 0 * 0, which is exact), the Philox draw -- is taken out of the tail of the kernel AND out
     // of its head: the operands are requested in `pre0`, i.e. behind the first operand transfers of the contraction, and
@@ -180,9 +188,9 @@ __device__ __forceinline__ void hidden_body(const HiddenArgs& a, int ms, int ns,
     auto pre = [&](int n_younger) {
         if (MODE == 0 && (a.s || a.s8)) {
             // one Philox block serves columns 4*(j0>>2) .. +3: this thread takes word j0 & 3
-            uint32_t prow = a.row0 + (uint32_t)row;
+            uint32_t prow = a.row0 + row_b + (uint32_t)row;
             asm volatile("" : "+v"(prow));   // the draw depends on this statement's position: it cannot be hoisted above the transfers
-            const f32x4 u4 = uniform4(a.seed, a.offset, prow, (uint32_t)(j0 >> 2));
+            const f32x4 u4 = uniform4(a.seed, a.offset + off_b, prow, (uint32_t)(j0 >> 2));
             const int e = j0 & 3;
             uu = e == 0 ? u4[0] : e == 1 ? u4[1] : e == 2 ? u4[2] : u4[3];
             asm volatile("" : "+v"(uu));   // ... nor sunk behind the wait below
@@ -242,7 +250,7 @@ __device__ __forceinline__ void hidden_body(const HiddenArgs& a, int ms, int ns,
     QBM_STAMP(12);
 }
 
-template <class TA, int FASTK, int MODE, int CM>
+template <class TA, int FASTK, int MODE, int CM, bool DB = false>
 __global__ __launch_bounds__(64 * H_NQ) void k_hidden(HiddenArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(64 * H_NQ) void k_hidden(HiddenArgs a)
     const int nM = (a.B + 16 * H_MT - 1) / (16 * H_MT), nN = (a.H + 16 * H_NT - 1) / (16 * H_NT);
     int ms, ns;
     strip_coords(nM, nN, ms, ns);
-    hidden_body<TA, FASTK, MODE, CM>(a, ms, ns, lds);
+    hidden_body<TA, FASTK, MODE, CM, 0, NoPre, DB>(a, ms, ns, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -447,6 +455,7 @@ struct VisibleArgs {
     // rows, one row each: -F, p(y|x0) and the row's two loss terms from x0.W + d (stored by the launch in front)
     int n_fe; const float* fe_pre; const int* fe_labels; float* fe_p; float* fe_rowloss;
     int fe_stage;             // the softplus terms of a monitor row staged through LDS (they fit behind the row's small arrays)
+    const uint64_t* draw_base;   // as HiddenArgs::draw_base (added to offset, offset_y and row0)
     uint32_t* hg_round;       // non-null: the fused tail of the step (k_hgrad) is the next launch: this one advances the word
                               // that launch takes its barrier round from (one writer, a kernel boundary in front of the readers:
                               // the same number in every workgroup whatever shapes earlier launches on the buffer had)
@@ -457,7 +466,7 @@ struct VisibleArgs {
 constexpr int V_NQ = 8;
 // The body of strip (ms, ns) of (16 MT) x (16 NT) outputs; the caller is a 512-thread workgroup.  AUX: cache policy of the
 // loads of h (kSc1 inside the fused chain kernel).
-template <class TA, bool FAST, int MT, int NT, int AUX = 0>
+template <class TA, bool FAST, int MT, int NT, int AUX = 0, bool DB = false>
 __device__ __forceinline__ void visible_body(const VisibleArgs& a, int ms, int ns, char* lds)
 {
     constexpr int NQ = V_NQ;
@@ -474,6 +483,9 @@ __device__ __forceinline__ void visible_body(const VisibleArgs& a, int ms, int n
     const bool pair = a.vecO && k0 + 1 < a.V;
     float bv[2] = {0.f, 0.f}, uu[2] = {0.f, 0.f};
     const uint32_t st_w = a.status ? *a.status : 0u;   // a scalar load issued here, consumed in front of the stores
+    uint64_t off_b = 0ull;
+    uint32_t row_b = 0u;
+    if constexpr (DB) { off_b = a.draw_base[0]; row_b = (uint32_t)a.draw_base[1]; }
     auto pre0 = [&]() {
         if (pair) {
             const float2 t = *reinterpret_cast<const float2*>(a.b + k0);
@@ -484,10 +496,10 @@ __device__ __forceinline__ void visible_body(const VisibleArgs& a, int ms, int n
         }
     };
     auto pre = [&](int) {
-        uint32_t prow = a.row0 + (uint32_t)i;
+        uint32_t prow = a.row0 + row_b + (uint32_t)i;
         asm volatile("" : "+v"(prow));     // the draw depends on this statement's position: not hoisted above the transfers,
         if (a.s || a.s8) {
-            const f32x4 u4 = uniform4(a.seed, a.offset, prow, (uint32_t)(k0 >> 2));
+            const f32x4 u4 = uniform4(a.seed, a.offset + off_b, prow, (uint32_t)(k0 >> 2));
             uu[0] = (k0 & 2) ? u4[2] : u4[0];   // this thread's pair is the lower or the upper half of the block
             uu[1] = (k0 & 2) ? u4[3] : u4[1];
         }
@@ -519,7 +531,7 @@ __device__ __forceinline__ void visible_body(const VisibleArgs& a, int ms, int n
     QBM_STAMP(12);
 }
 
-template <class TA, bool FAST, int CM>
+template <class TA, bool FAST, int CM, bool DB = false>
 __global__ __launch_bounds__(64 * V_NQ) void k_visible(VisibleArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -537,8 +549,10 @@ __global__ __launch_bounds__(64 * V_NQ) void k_visible(VisibleArgs a)
         // the shortest path to y (a wavefront that has ended takes no part in the workgroup's barriers)
         if ((int)blockIdx.x < a.n_aux) {
             if (threadIdx.x >= 256) return;
-            class_row<TA, CM>(a.h, a.U, a.cb, a.py, a.ys, (int)blockIdx.x, a.H, a.C, a.seed, a.offset_y, a.row0,
-                              reinterpret_cast<float*>(lds));
+            uint64_t oy = a.offset_y;
+            uint32_t r0 = a.row0;
+            if constexpr (DB) { oy += a.draw_base[0]; r0 += (uint32_t)a.draw_base[1]; }
+            class_row<TA, CM>(a.h, a.U, a.cb, a.py, a.ys, (int)blockIdx.x, a.H, a.C, a.seed, oy, r0, reinterpret_cast<float*>(lds));
             return;
         }
         if ((int)blockIdx.x < a.n_aux + a.n_fe) {   // the monitor: one row per workgroup, its classes dealt to the 8 wavefronts (in
@@ -553,8 +567,12 @@ __global__ __launch_bounds__(64 * V_NQ) void k_visible(VisibleArgs a)
         // large minibatches: 8 rows per aux workgroup, one per wavefront, dealt BEHIND the strips (they fill the ragged end of
         // the launch instead of standing in front of it)
         const int i = ((int)blockIdx.x - nMs * nNs) * V_NQ + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-        if (i < a.B)
-            class_row_wave<TA, CM>(a.h, a.U, a.cb, a.py, a.ys, i, a.H, a.C, a.seed, a.offset_y, a.row0, (int)threadIdx.x & 63);
+        if (i < a.B) {
+            uint64_t oy = a.offset_y;
+            uint32_t r0 = a.row0;
+            if constexpr (DB) { oy += a.draw_base[0]; r0 += (uint32_t)a.draw_base[1]; }
+            class_row_wave<TA, CM>(a.h, a.U, a.cb, a.py, a.ys, i, a.H, a.C, a.seed, oy, r0, (int)threadIdx.x & 63);
+        }
         return;
     }
     QBM_STAMP(10);
@@ -566,7 +584,7 @@ __global__ __launch_bounds__(64 * V_NQ) void k_visible(VisibleArgs a)
     } else {
         strip_coords(nMs, nNs, ms, ns, 0);
     }
-    visible_body<TA, FAST, V_MT, V_NT>(a, ms, ns, lds);
+    visible_body<TA, FAST, V_MT, V_NT, 0, DB>(a, ms, ns, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -735,14 +753,14 @@ __global__ __launch_bounds__(512) void k_chain(ChainArgs a)
         if (hidden) {
             if (j < nNh) {
                 const HiddenArgs ha{vin, yin, a.W, a.d, a.U, pout, nullptr, hout, a.B, a.V, a.H, a.C, a.KPh, a.seed, off, a.row0,
-                                    true, a.ldsCls, nullptr, nullptr};
+                                    true, a.ldsCls, nullptr, nullptr, nullptr};
                 hidden_body<uint8_t, 2, 0, CM, kSc1>(ha, g, j, lds + a.ldsT, lds, w_resident);
                 w_resident = true;
             }
         } else {
             if (j < nNv) {
                 const VisibleArgs va{a.h, a.W, a.b, nullptr, nullptr, vout, a.B, a.V, a.H, a.KPv, a.seed, off - 2, a.row0, a.vecO,
-                                     a.U, a.c, nullptr, yout, a.C, off - 1, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
+                                     a.U, a.c, nullptr, yout, a.C, off - 1, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
                 visible_body<uint8_t, true, 2, 2, kSc1>(va, g, j, lds + a.ldsT);
             }
             // class conditional of the block's 32 rows, one row per wavefront, on the workgroups that have no strip -- or,
@@ -1754,12 +1772,13 @@ struct HiddenPlan {
 
 template <class TA>
 HiddenPlan plan_hidden(const qbm_rbm_params* P, const void* v, const float* y, int B, float* p, float* s, uint8_t* s8, int mode,
-                       uint64_t seed, uint64_t offset, uint32_t row0, float* pre_out, const uint32_t* status)
+                       uint64_t seed, uint64_t offset, uint32_t row0, float* pre_out, const uint32_t* status,
+                       const uint64_t* draw_base = nullptr)
 {
     constexpr int ASZ = (int)sizeof(TA), MT = H_MT, NT = H_NT, NQ = H_NQ;
     constexpr int kScratch = NQ * 1024;   // one 1 KiB transfer slot per wavefront for the epilogue operands
     HiddenArgs a{v, y, P->W, P->d, P->U, p, s, s8, B, P->V, P->H, P->C, panel_for_nq<MT, NT, ASZ, NQ>(P->V, kScratch), seed,
-                 offset, row0, false, 0, mode == 0 ? pre_out : nullptr, status};
+                 offset, row0, false, 0, mode == 0 ? pre_out : nullptr, status, draw_base};
     // LDS-DMA path: whole 16-k pieces, 16-byte aligned units, descriptors below 2 GiB
     const bool fast = (P->V % 16 == 0) && aligned16(v) && (P->H % 4 == 0) && aligned16(P->W) &&
                       small2g((long)B * P->V, ASZ) && small2g((long)P->V * P->H, 4);
@@ -1790,18 +1809,23 @@ HiddenPlan plan_hidden(const qbm_rbm_params* P, const void* v, const float* y, i
 template <class TA>
 int launch_hidden_t(const qbm_rbm_params* P, const void* v, const float* y, int B, float* p, float* s, uint8_t* s8,
                     int mode, uint64_t seed, uint64_t offset, uint32_t row0, hipStream_t st, float* pre_out,
-                    const uint32_t* status)
+                    const uint32_t* status, const uint64_t* draw_base)
 {
     constexpr int NQ = H_NQ;
-    const HiddenPlan hp = plan_hidden<TA>(P, v, y, B, p, s, s8, mode, seed, offset, row0, pre_out, status);
+    const HiddenPlan hp = plan_hidden<TA>(P, v, y, B, p, s, s8, mode, seed, offset, row0, pre_out, status, draw_base);
     const HiddenArgs& a = hp.a;
     const size_t lds = hp.lds;
     const bool fast = hp.fast;
     const int nM = hp.nM, nN = hp.nN;
 #define QBM_LAUNCH(F, MODE, CM)                                                                      \
     {                                                                                                \
-        if (int rc = set_lds(k_hidden<TA, F, MODE, CM>, lds)) return rc;                             \
-        hipLaunchKernelGGL((k_hidden<TA, F, MODE, CM>), dim3(nM * nN), dim3(64 * NQ), lds, st, a);   \
+        if (MODE == 0 && a.draw_base) {                                                                                   \
+            if (int rc = set_lds(k_hidden<TA, F, 0, CM, true>, lds)) return rc;                                           \
+            hipLaunchKernelGGL((k_hidden<TA, F, 0, CM, true>), dim3(nM * nN), dim3(64 * NQ), lds, st, a);                 \
+        } else {                                                                                                          \
+            if (int rc = set_lds(k_hidden<TA, F, MODE, CM>, lds)) return rc;                                              \
+            hipLaunchKernelGGL((k_hidden<TA, F, MODE, CM>), dim3(nM * nN), dim3(64 * NQ), lds, st, a);                    \
+        }                                                                                                                 \
     }
     if (mode != 0 || !y) {  // no class term: the class-count bucket is irrelevant
 #define QBM_LF(MODE, CM) { if (a.epiDma) QBM_LAUNCH(2, MODE, CM) else if (fast) QBM_LAUNCH(1, MODE, CM) else QBM_LAUNCH(0, MODE, CM) }
@@ -1819,17 +1843,17 @@ int launch_hidden_t(const qbm_rbm_params* P, const void* v, const float* y, int 
 
 int launch_hidden(const qbm_rbm_params* P, const void* v, int v_dtype, const float* y, int B, float* p, float* s,
                   uint8_t* s8, int mode, uint64_t seed, uint64_t offset, uint32_t row0, hipStream_t st, float* pre_out = nullptr,
-                  const uint32_t* status = nullptr)
+                  const uint32_t* status = nullptr, const uint64_t* draw_base = nullptr)
 {
-    return v_dtype == QBM_U8 ? launch_hidden_t<uint8_t>(P, v, y, B, p, s, s8, mode, seed, offset, row0, st, pre_out, status)
-                             : launch_hidden_t<float>(P, v, y, B, p, s, s8, mode, seed, offset, row0, st, pre_out, status);
+    return v_dtype == QBM_U8 ? launch_hidden_t<uint8_t>(P, v, y, B, p, s, s8, mode, seed, offset, row0, st, pre_out, status, draw_base)
+                             : launch_hidden_t<float>(P, v, y, B, p, s, s8, mode, seed, offset, row0, st, pre_out, status, draw_base);
 }
 
 // sample_visible, optionally with the class conditional riding along as aux workgroups
 template <class TA>
 int launch_visible_t(const qbm_rbm_params* P, const void* h, int B, float* p_v, float* v_s, uint8_t* v_s8, float* p_y,
                      float* y1hot, uint64_t seed, uint64_t offset_v, uint64_t offset_y, uint32_t row0, hipStream_t st,
-                     const uint32_t* status, uint32_t* hg_round, const qbm_rbm_cd_workspace* mon)
+                     const uint32_t* status, uint32_t* hg_round, const qbm_rbm_cd_workspace* mon, const uint64_t* draw_base)
 {
     constexpr int ASZ = (int)sizeof(TA), MT = V_MT, NT = V_NT, NQ = V_NQ;
     const bool with_class = p_y || y1hot;
@@ -1839,7 +1863,7 @@ int launch_visible_t(const qbm_rbm_params* P, const void* h, int B, float* p_v, 
                   (P->V % 2 == 0) && (!p_v || aligned8(p_v)) && (!v_s || aligned8(v_s)) && (!v_s8 || aligned2(v_s8)) &&
                       aligned8(P->b),
                   P->U, P->c, p_y, y1hot, P->C, offset_y, with_class ? (B <= 512 ? B : (B + NQ - 1) / NQ) : 0, status, 0, nullptr, nullptr, nullptr, nullptr, 0,
-                  status ? hg_round : nullptr};
+                  draw_base, status ? hg_round : nullptr};
     if (mon && a.n_aux == B) {   // (visible_takes_monitor: the caller has asked)
         a.n_fe = B; a.fe_pre = mon->mon_pre; a.fe_labels = mon->mon_labels; a.fe_p = mon->mon_p; a.fe_rowloss = mon->mon_rowloss;
     }
@@ -1852,8 +1876,13 @@ int launch_visible_t(const qbm_rbm_params* P, const void* h, int B, float* p_v, 
     a.fe_stage = a.n_fe > 0 && P->C < NQ && 1280 + (size_t)P->C * P->H * sizeof(float) <= lds;
 #define QBM_LAUNCH(F, CM)                                                                       \
     {                                                                                           \
-        if (int rc = set_lds(k_visible<TA, F, CM>, lds)) return rc;                             \
-        hipLaunchKernelGGL((k_visible<TA, F, CM>), dim3(grid), dim3(64 * NQ), lds, st, a);      \
+        if (a.draw_base) {                                                                            \
+            if (int rc = set_lds(k_visible<TA, F, CM, true>, lds)) return rc;                         \
+            hipLaunchKernelGGL((k_visible<TA, F, CM, true>), dim3(grid), dim3(64 * NQ), lds, st, a);  \
+        } else {                                                                                      \
+            if (int rc = set_lds(k_visible<TA, F, CM>, lds)) return rc;                               \
+            hipLaunchKernelGGL((k_visible<TA, F, CM>), dim3(grid), dim3(64 * NQ), lds, st, a);        \
+        }                                                                                             \
     }
 #define QBM_L(CM) { if (fast) QBM_LAUNCH(true, CM) else QBM_LAUNCH(false, CM) }
     if (!with_class) { QBM_L(2) }
@@ -1867,11 +1896,11 @@ int launch_visible_t(const qbm_rbm_params* P, const void* h, int B, float* p_v, 
 int launch_visible(const qbm_rbm_params* P, const void* h, int h_dtype, int B, float* p_v, float* v_s, uint8_t* v_s8,
                    float* p_y, float* y1hot, uint64_t seed, uint64_t offset_v, uint64_t offset_y, uint32_t row0,
                    hipStream_t st, const uint32_t* status = nullptr, uint32_t* hg_round = nullptr,
-                   const qbm_rbm_cd_workspace* mon = nullptr)
+                   const qbm_rbm_cd_workspace* mon = nullptr, const uint64_t* draw_base = nullptr)
 {
     return h_dtype == QBM_U8
-               ? launch_visible_t<uint8_t>(P, h, B, p_v, v_s, v_s8, p_y, y1hot, seed, offset_v, offset_y, row0, st, status, hg_round, mon)
-               : launch_visible_t<float>(P, h, B, p_v, v_s, v_s8, p_y, y1hot, seed, offset_v, offset_y, row0, st, status, hg_round, mon);
+               ? launch_visible_t<uint8_t>(P, h, B, p_v, v_s, v_s8, p_y, y1hot, seed, offset_v, offset_y, row0, st, status, hg_round, mon, draw_base)
+               : launch_visible_t<float>(P, h, B, p_v, v_s, v_s8, p_y, y1hot, seed, offset_v, offset_y, row0, st, status, hg_round, mon, draw_base);
 }
 
 // Does the k_visible launch of a CD step carry the training loop's monitor (one aux workgroup per row)?  Only where the
@@ -2029,7 +2058,7 @@ int launch_chain_fused(const qbm_rbm_params* P, const void* v0, int v0_dtype, co
     // of W into every XCD, 12.8 MB instead of 1.6, which costs what the two saved launch boundaries gain; measured
     // 30.0 vs 29.9 us per step; PCD-10: 136 vs 160)
     const bool enabled = device_fits && (mode == 2 || ((mode == 1 || mode == 3) && k >= 2));
-    if (!enabled || !ws->sync || v0_dtype != QBM_U8) return QBM_OK;
+    if (!enabled || !ws->sync || v0_dtype != QBM_U8 || ws->draw_base) return QBM_OK;   // (device-side draw counters: launch per phase)
     const int V = P->V, H = P->H, C = P->C;
     if (B % 32 != 0 || B > 256 || H % 16 != 0 || H > 512 || V % 16 != 0 || V > 1024 || 5 * C + 4 > 64) return QBM_OK;
     const void* ptrs[] = {v0, y0, P->W, P->b, P->d, P->U, ws->h, ws->vk, ws->yk, chain_v, chain_y};
@@ -2070,7 +2099,7 @@ bool hgrad_eligible(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void*
 {
     // mode 3 only: measured slower than the launch-per-phase tail on every shape tried -- kept as an
     // opt-in, with its tests, next to the numbers that say why
-    if (fused_chain_mode() != 3 || !device_has_8x32_cus() || !ws || !ws->sync || v0_dtype != QBM_U8) return false;
+    if (fused_chain_mode() != 3 || !device_has_8x32_cus() || !ws || !ws->sync || v0_dtype != QBM_U8 || ws->draw_base) return false;
     const int V = P->V, H = P->H, C = P->C;
     const int nM = (B + 16 * H_MT - 1) / (16 * H_MT), nN = (H + 16 * H_NT - 1) / (16 * H_NT);
     // (B <= 256: one panel of 64 rows per K chain of the gradient -- its operands are requested in one go under the hidden phase)
@@ -2311,12 +2340,13 @@ static int cd_chain_impl(const qbm_rbm_params* P, const void* v0, int v0_dtype, 
         if (done) return QBM_OK;
     }
     // (mon_pre: the training loop's monitor wants v0.W + d -- one more store of the positive-phase launch)
+    const uint64_t* db = ws->draw_base;   // device-side draw counters (added to offset / row0 by every sampling launch), or null
     if (chain_v) {
         // positive phase on the data (probabilities only), negative chain from the persistent state
-        if (int rc = launch_hidden(P, v0, v0_dtype, y0, B, ws->ph0, nullptr, nullptr, 0, seed, offset, row0, st, mon_pre, hg_status)) return rc;
-        if (int rc = launch_hidden(P, chain_v, QBM_U8, chain_y, B, nullptr, nullptr, ws->h, 0, seed, offset, row0, st, nullptr, hg_status)) return rc;
+        if (int rc = launch_hidden(P, v0, v0_dtype, y0, B, ws->ph0, nullptr, nullptr, 0, seed, offset, row0, st, mon_pre, hg_status, db)) return rc;
+        if (int rc = launch_hidden(P, chain_v, QBM_U8, chain_y, B, nullptr, nullptr, ws->h, 0, seed, offset, row0, st, nullptr, hg_status, db)) return rc;
     } else {
-        if (int rc = launch_hidden(P, v0, v0_dtype, y0, B, ws->ph0, nullptr, ws->h, 0, seed, offset, row0, st, mon_pre, hg_status)) return rc;
+        if (int rc = launch_hidden(P, v0, v0_dtype, y0, B, ws->ph0, nullptr, ws->h, 0, seed, offset, row0, st, mon_pre, hg_status, db)) return rc;
     }
     for (int t = 1; t <= k; ++t) {
         const uint64_t o = offset + 3ull * (uint64_t)t;
@@ -2325,11 +2355,11 @@ static int cd_chain_impl(const qbm_rbm_params* P, const void* v0, int v0_dtype, 
         float* y_out = (chain_v && t == k) ? chain_y : ws->yk;
         // v_t and y_t both depend on h_{t-1} only: one launch (class conditional as aux workgroups)
         if (int rc = launch_visible(P, ws->h, QBM_U8, B, nullptr, nullptr, v_out, nullptr, y_out, seed, o - 2, o - 1, row0, st, hg_status,
-                                    (t == k && defer_last) ? ws->sync + kHgRound : nullptr, (t == 1 && mon_in_visible) ? ws : nullptr))
+                                    (t == k && defer_last) ? ws->sync + kHgRound : nullptr, (t == 1 && mon_in_visible) ? ws : nullptr, db))
             return rc;
         if (t == k && defer_last) break;
         // the hidden SAMPLE of the last iteration has no consumer (the gradient uses p(h_k)): no draw, no store
-        if (int rc = launch_hidden(P, v_out, QBM_U8, y_out, B, ws->phk, nullptr, t < k ? ws->h : nullptr, 0, seed, o, row0, st, nullptr, hg_status))
+        if (int rc = launch_hidden(P, v_out, QBM_U8, y_out, B, ws->phk, nullptr, t < k ? ws->h : nullptr, 0, seed, o, row0, st, nullptr, hg_status, db))
             return rc;
     }
     return QBM_OK;

@@ -223,7 +223,7 @@ class HipRbmOps:
         return p_out
 
     def cd_step(self, P: ParamSet, G: GradSet, v0, y0, k, seed, offset, row0, chain_v, chain_y, fuse, lr, factor,
-                batch_size, sparse, ws=None, with_count=False, replay=None, monitor=None):
+                batch_size, sparse, ws=None, with_count=False, replay=None, monitor=None, draw_base=None):
         """CD-k / PCD step: chain + gradient (+ fused update when `fuse`).
         monitor: (labels int32 [B] device tensor, loss_acc float64 [2] device tensor) -- the training loop's bookkeeping: the
         step also evaluates p(y|x0) under the parameters before its update and adds the minibatch's two loss terms to
@@ -232,6 +232,9 @@ class HipRbmOps:
         with_count: the gradient launch also stores its row count in G.count (the data-parallel path all-reduces it).
         replay: what to call to repeat this step should its one-launch chain give up (default: this call again; the
         data-parallel caller passes chain + all-reduce + update).
+        draw_base: int64 / uint64 [2] device tensor added on the device to (offset, row0) by every sampling launch
+        (include/qbm_hip.h: qbm_rbm_cd_workspace.draw_base): a loop that captures its steps in a hipGraph passes offsets relative
+        to the epoch and moves the two words between replays; the workspaces cd_step keeps only.
         -> (ph0 f32, h u8, vk u8, yk f32, phk f32); with persistent chains (v_k, y_k) ARE chain_v / chain_y."""
         v0, vd = _state(v0, self.device)
         y0 = _f32(y0, self.device)
@@ -253,10 +256,11 @@ class HipRbmOps:
                 cws.mon_labels, cws.mon_loss_acc = ptr(monitor[0]), ptr(monitor[1])
             else:
                 cws.mon_labels = None
+            cws.draw_base = ptr(draw_base) if draw_base is not None else None
         check(self.lib.qbm_rbm_cd_step(C.byref(P.struct()), C.byref(G.struct(with_count=with_count)), ptr(v0), vd, ptr(y0), B, k,
                                        seed, offset, row0, ptr(chain_v), ptr(chain_y), C.byref(cws), int(fuse), lr, factor,
                                        batch_size, sparse, current_stream()), "qbm_rbm_cd_step")
-        if own_ws and ws[5] is not None and self._may_fuse(k, vd):
+        if own_ws and ws[5] is not None and draw_base is None and self._may_fuse(k, vd):
             # a launch that synchronises workgroups inside an XCD may have run (the one-launch chain, or the fused tail: last
             # hidden phase + gradient + update): keep what it takes to repeat the step on the launch-per-phase path -- and, for
             # a fused tail with the update inside, to FINISH it (qbm_rbm_cd_step_finish: part of the update may have been

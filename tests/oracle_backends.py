@@ -162,7 +162,9 @@ class OracleRbmOps:
         return torch.from_numpy(p)
 
     def cd_step(self, P, G, v0, y0, k, seed, offset, row0, chain_v, chain_y, fuse, lr, factor, batch_size, sparse,
-                ws=None, with_count=False, replay=None, monitor=None):
+                ws=None, with_count=False, replay=None, monitor=None, draw_base=None):
+        if draw_base is not None:      # qbm_rbm_cd_workspace.draw_base: device words added to (offset, row0)
+            offset, row0 = offset + int(draw_base[0]), (row0 + int(draw_base[1])) & 0xFFFFFFFF
         if with_count:
             G.count.fill_(float(len(v0)))
         if len(v0) == 0:

@@ -176,3 +176,55 @@ def test_discriminative_epochs_replayed_from_one_graph_equal_eager_epochs(dops, 
     assert len(set(outs[0][0])) == 4                                   # the epochs differ: the replay trained on
     for a, b in zip(outs[0][2], outs[1][2]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("storage", ["bits", "f32"])
+def test_generative_epochs_replayed_from_one_graph_equal_eager_epochs(dops, storage, monkeypatch):
+    """train_rbm(method='generative'), CD-1, from a DeviceDataset: the epoch's launches are captured with draw ids and Philox
+    rows RELATIVE to the epoch, two device words (qbm_rbm_cd_workspace.draw_base) carry the epoch's base and are moved between
+    replays -- the draws, the monitor's loss sums and the parameters equal the eager loop's (QBM_EPOCH_GRAPH=0) bit for bit over
+    four epochs with a short last minibatch; and a second train_rbm call on the same object goes on from the captured graph."""
+    from qbm_image_classification_amd.classification_rbm import ClassificationRBM
+    from qbm_image_classification_amd.device_data import DeviceDataset
+
+    x, y = _set(150, 784, classes=2, seed=11)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("QBM_EPOCH_GRAPH", flag)
+        m = ClassificationRBM(784, 64, 1, num_classes=2, learning_rate=0.05, seed=2, device="cuda:0")
+        ds = DeviceDataset(x, y, batch_size=32, num_classes=2, storage=storage, seed=4)
+        loss, _, nll = m.train_rbm(ds, epochs=3, method="generative")
+        loss2, _, nll2 = m.train_rbm(ds, epochs=1, method="generative")
+        outs.append((loss + loss2, nll + nll2, m._draw_offset, m._rows_seen,
+                     [getattr(m, nm).clone() for nm in ("weights", "visible_bias", "hidden_bias", "class_weights", "class_bias")]))
+        assert (m._epoch_graph is not None) == (flag == "1")
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1] and outs[0][2:4] == outs[1][2:4]
+    assert len(set(outs[0][0])) == 4
+    for a, b in zip(outs[0][4], outs[1][4]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_device_side_draw_counters_equal_host_side_offsets(dops):
+    """qbm_rbm_cd_workspace.draw_base: a CD-2 / PCD step (launch per phase) with (offset, row0) = (5, 7) in the arguments and
+    (1000, 2^32 - 3) in the two device words == the same step with (1005, 4) in the arguments: every sampled bit and parameter."""
+    from qbm_image_classification_amd.rbm_ops import GradSet, HipRbmOps, ParamSet
+
+    ops = HipRbmOps("cuda:0")
+    rs = np.random.RandomState(3)
+    V, H, C, B = 784, 128, 2, 64
+    mk = lambda: ParamSet(*(torch.from_numpy(a).cuda() for a in ((rs2.standard_normal((V, H)) * 0.1).astype(np.float32), np.zeros(V, np.float32),
+                                                                 np.zeros(H, np.float32), (rs2.standard_normal((C, H)) * 0.1).astype(np.float32),
+                                                                 np.zeros(C, np.float32))))
+    v0 = torch.from_numpy((rs.random_sample((B, V)) < 0.3).astype(np.uint8)).cuda()
+    y0 = torch.nn.functional.one_hot(torch.from_numpy(rs.randint(0, C, B)), C).float().cuda()
+    res = []
+    for base, off, row0 in ((torch.tensor([1000, 2 ** 32 - 3], dtype=torch.int64).cuda(), 5, 7), (None, 1005, 4)):
+        rs2 = np.random.RandomState(8)
+        P, G = mk(), GradSet(V, H, C, ops.device)
+        cv, cy = v0.roll(1, 0).clone(), y0.roll(1, 0).clone()
+        ops.cd_step(P, G, v0, y0, 2, 9, off, row0, cv, cy, True, 0.05, 1.0, float(B), 0.0, draw_base=base)
+        res.append([t.clone() for t in (P.W, P.d, P.U, cv, cy)])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

@@ -97,10 +97,10 @@ def rbm_lines(n_images, reps):
             raw_mon()
             t_mon = best_of(raw_mon, reps)
             ops.check_chain_status()
-        # the discriminative rule from a device-resident dataset: epochs replayed from ONE captured hipGraph (the second epoch of
-        # a fresh object captures it; here the warm-up call did) -- 3 epochs per call, per-epoch time
+        # from a device-resident dataset the discriminative rule and CD-1 replay their epochs from ONE captured hipGraph (the
+        # second epoch of a fresh object captures it) -- 3 epochs per call, per-epoch time
         t_graph = None
-        if method == "discriminative":
+        if method == "discriminative" or (k == 1 and not pcd):
             def three():
                 with contextlib.redirect_stdout(io.StringIO()):
                     rbm.train_rbm(ds, epochs=3, method=method)
