@@ -333,7 +333,9 @@ class ClassificationRBM:
                 # step performs the epoch's gather into the dataset's buffers; the minibatches it yields are the same views in
                 # every epoch.
                 views = list(batches)
-                key = (id(getattr(train_loader, 'last_views', None)), len(views), views[0][0].data_ptr() if views else 0) + (
+                key = (id(getattr(train_loader, 'last_views', None)), len(views), views[0][0].data_ptr() if views else 0,
+                       views[0][1].data_ptr() if views else 0, getattr(train_loader, 'N', None), getattr(train_loader, 'batch_size', None),
+                       views[-1][0].shape[0] if views else 0) + (
                     id(self._params()), float(self.learning_rate), float(self.sparse_constant), float(discriminative_factor), self.keep_grads,
                     method, float(gen_factor), self.k, self.persistent)
                 if epoch_graph is None or epoch_graph[0] != key:

@@ -628,6 +628,7 @@ struct ChainArgs {
     uint64_t seed, offset;
     uint32_t row0;
     bool vecO;
+    float* mon_pre;      // non-null: the first hidden phase also stores v0.W + d (the training loop's monitor)
 };
 
 constexpr int kChainSpin = 1 << 20;   // polls (>= 0.3 us each) before a barrier gives up
@@ -753,7 +754,7 @@ __global__ __launch_bounds__(512) void k_chain(ChainArgs a)
         if (hidden) {
             if (j < nNh) {
                 const HiddenArgs ha{vin, yin, a.W, a.d, a.U, pout, nullptr, hout, a.B, a.V, a.H, a.C, a.KPh, a.seed, off, a.row0,
-                                    true, a.ldsCls, nullptr, nullptr, nullptr};
+                                    true, a.ldsCls, ph == 0 ? a.mon_pre : nullptr, nullptr, nullptr};
                 hidden_body<uint8_t, 2, 0, CM, kSc1>(ha, g, j, lds + a.ldsT, lds, w_resident);
                 w_resident = true;
             }
@@ -2049,7 +2050,7 @@ bool device_has_8x32_cus()
 // has to run instead.
 int launch_chain_fused(const qbm_rbm_params* P, const void* v0, int v0_dtype, const float* y0, int B, int k, uint64_t seed,
                        uint64_t offset, uint32_t row0, uint8_t* chain_v, float* chain_y, const qbm_rbm_cd_workspace* ws,
-                       hipStream_t st, bool* done)
+                       hipStream_t st, bool* done, float* mon_pre)
 {
     *done = false;
     const bool device_fits = device_has_8x32_cus();
@@ -2069,7 +2070,7 @@ int launch_chain_fused(const qbm_rbm_params* P, const void* v0, int v0_dtype, co
     constexpr int kScratch = NQ * 1024;
     ChainArgs a{P->W, P->b, P->d, P->U, P->c, (const uint8_t*)v0, y0, chain_v, chain_y, ws->ph0, ws->h, ws->vk, ws->yk, ws->phk,
                 ws->sync, B, V, H, C, k, (chain_len(V, NQ) + 63) / 64 * 64, panel_for_nq<2, 2, 1, NQ>(H, 0), 0, 0, seed,
-                offset, row0, V % 2 == 0};
+                offset, row0, V % 2 == 0, mon_pre};
     // LDS: [W panel of the hidden phases, resident | transient: A tiles + epilogue scratch of a hidden phase, or the whole
     // staging of a visible phase].  One panel per chain in the hidden phases (the resident image IS the whole chain).
     if (a.KPh < chain_len(V, NQ)) return QBM_OK;
@@ -2335,7 +2336,7 @@ static int cd_chain_impl(const qbm_rbm_params* P, const void* v0, int v0_dtype, 
     hipStream_t st = (hipStream_t)stream;
     {   // one launch for the whole chain where the shape allows it (B <= 256 in blocks of 32 rows, uint8 data)
         bool done = false;
-        if (int rc = launch_chain_fused(P, v0, v0_dtype, y0, B, k, seed, offset, row0, chain_v, chain_y, ws, st, &done)) return rc;
+        if (int rc = launch_chain_fused(P, v0, v0_dtype, y0, B, k, seed, offset, row0, chain_v, chain_y, ws, st, &done, mon_pre)) return rc;
         *fused = done;
         if (done) return QBM_OK;
     }
@@ -2403,9 +2404,7 @@ int qbm_rbm_cd_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void*
     if (!(batch_size > 0.f)) return fail(QBM_ERR_ARG, "cd_step: batch_size must be positive");
     if (mon && (fused || !mon_vis)) {
         hipStream_t st = (hipStream_t)stream;
-        // the one-launch chain does not deliver v0.W + d: one contraction of its own
-        if (fused)
-            if (int rc = launch_hidden(P, v0, v0_dtype, nullptr, B, ws->mon_pre, nullptr, nullptr, 1, 0, 0, 0, st)) return rc;
+        // (the one-launch chain stores v0.W + d in its first hidden phase, like the launch-per-phase path)
 #define QBM_L(CM) \
     launch_free_energy<CM>(ws->mon_pre, P->U, P->c, nullptr, ws->mon_p, B, P->H, P->C, ws->mon_labels, nullptr, ws->mon_rowloss, hg_status, st)
         QBM_DISPATCH_CM(P->C, QBM_L);
