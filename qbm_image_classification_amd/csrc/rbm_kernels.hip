@@ -58,9 +58,12 @@ constexpr int G_MT = 4;
         else { MACRO(QBM_MAX_CLASSES); }            \
     } while (0)
 
-// Device-side draw counters (HiddenArgs / VisibleArgs::draw_base) are a COMPILE-TIME variant of the sampling kernels (DB): read
-// at run time behind a null test they cost k_visible 0.7 us per launch, read unconditionally from a zero pair still 0.2 us --
-// the default path carries none of it.
+// The status word and the device-side draw counters (HiddenArgs / VisibleArgs::status, ::draw_base) are read by a COMPILE-TIME
+// variant of the sampling kernels only (XA, "extra arguments": launched when either pointer is set -- the opt-in fused tail, a
+// captured generative epoch).  Read at run time behind a null test the counters cost k_visible 0.7 us per launch, read
+// unconditionally from a zero pair still 0.2 us, the status word a few hundredths: the default path carries none of it.  Inside
+// the variant a null pointer is replaced by the address of zeros (a select, no branch).
+static __device__ unsigned long long g_zero_base[2] = {0ull, 0ull};
 template <class T> struct KView;   // K-contiguous A operand of element type T
 template <> struct KView<float> { using type = ViewKContig; };
 template <> struct KView<uint8_t> { using type = ViewKContigU8; };
@@ -114,7 +117,7 @@ constexpr int H_NQ = 8;
 // AUX: cache policy of the loads of v and y (kSc1 inside the fused chain kernel: another workgroup of the XCD wrote them
 // during this launch; FASTK == 2 only).  The body of strip (ms, ns); the caller is a 512-thread workgroup.
 // post: strip_mma's hook between the contraction and the combine (k_hgrad requests the gradient's operands there)
-template <class TA, int FASTK, int MODE, int CM, int AUX = 0, class Post = NoPre, bool DB = false>
+template <class TA, int FASTK, int MODE, int CM, int AUX = 0, class Post = NoPre, bool XA = false>
 __device__ __forceinline__ void hidden_body(const HiddenArgs& a, int ms, int ns, char* lds, char* ldsB = nullptr,
                                             bool b_resident = false, Post&& post = NoPre{})
 {
@@ -130,10 +133,14 @@ __device__ __forceinline__ void hidden_body(const HiddenArgs& a, int ms, int ns,
     const int row = m0 + SO::row(0), j0 = n0 + SO::cg(0);
     const int i_c = min(row, a.B - 1), j_c = min(j0, a.H - 1);
     const bool with_cls = MODE == 0 && a.y != nullptr;
-    const uint32_t st_w = a.status ? *a.status : 0u;   // a scalar load issued here, consumed in front of the stores
-    uint64_t off_b = 0ull;   // (DB: loaded here, consumed in `pre`, behind the first transfers)
+    uint32_t st_w = 0u;      // (XA: scalar loads issued here; the status word is consumed in front of the stores, the draw
+    uint64_t off_b = 0ull;   //  counters in `pre`, behind the first transfers)
     uint32_t row_b = 0u;
-    if constexpr (DB) { off_b = a.draw_base[0]; row_b = (uint32_t)a.draw_base[1]; }
+    if constexpr (XA) {
+        const unsigned long long* db = a.draw_base ? reinterpret_cast<const unsigned long long*>(a.draw_base) : g_zero_base;
+        const uint32_t* sp = a.status ? a.status : reinterpret_cast<const uint32_t*>(g_zero_base);
+        st_w = *sp; off_b = db[0]; row_b = (uint32_t)db[1];
+    }
     // Everything of the epilogue that does not depend on the contraction -- bias and class-term operands, the class chain
     // (classes c >= C enter it as 0 * 0, which is exact), the Philox draw -- is taken out of the tail of the kernel AND out
     // of its head: the operands are requested in `pre0`, i.e. behind the first operand transfers of the contraction, and
@@ -250,7 +257,7 @@ __device__ __forceinline__ void hidden_body(const HiddenArgs& a, int ms, int ns,
     QBM_STAMP(12);
 }
 
-template <class TA, int FASTK, int MODE, int CM, bool DB = false>
+template <class TA, int FASTK, int MODE, int CM, bool XA = false>
 __global__ __launch_bounds__(64 * H_NQ) void k_hidden(HiddenArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(64 * H_NQ) void k_hidden(HiddenArgs a)
     const int nM = (a.B + 16 * H_MT - 1) / (16 * H_MT), nN = (a.H + 16 * H_NT - 1) / (16 * H_NT);
     int ms, ns;
     strip_coords(nM, nN, ms, ns);
-    hidden_body<TA, FASTK, MODE, CM, 0, NoPre, DB>(a, ms, ns, lds);
+    hidden_body<TA, FASTK, MODE, CM, 0, NoPre, XA>(a, ms, ns, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -466,7 +473,7 @@ struct VisibleArgs {
 constexpr int V_NQ = 8;
 // The body of strip (ms, ns) of (16 MT) x (16 NT) outputs; the caller is a 512-thread workgroup.  AUX: cache policy of the
 // loads of h (kSc1 inside the fused chain kernel).
-template <class TA, bool FAST, int MT, int NT, int AUX = 0, bool DB = false>
+template <class TA, bool FAST, int MT, int NT, int AUX = 0, bool XA = false>
 __device__ __forceinline__ void visible_body(const VisibleArgs& a, int ms, int ns, char* lds)
 {
     constexpr int NQ = V_NQ;
@@ -482,10 +489,14 @@ __device__ __forceinline__ void visible_body(const VisibleArgs& a, int ms, int n
     const int i = m0 + SO::row(0), k0 = n0 + 2 * SO::cg(0);
     const bool pair = a.vecO && k0 + 1 < a.V;
     float bv[2] = {0.f, 0.f}, uu[2] = {0.f, 0.f};
-    const uint32_t st_w = a.status ? *a.status : 0u;   // a scalar load issued here, consumed in front of the stores
+    uint32_t st_w = 0u;
     uint64_t off_b = 0ull;
     uint32_t row_b = 0u;
-    if constexpr (DB) { off_b = a.draw_base[0]; row_b = (uint32_t)a.draw_base[1]; }
+    if constexpr (XA) {   // (scalar loads issued here, consumed in `pre` / in front of the stores: see hidden_body)
+        const unsigned long long* db = a.draw_base ? reinterpret_cast<const unsigned long long*>(a.draw_base) : g_zero_base;
+        const uint32_t* sp = a.status ? a.status : reinterpret_cast<const uint32_t*>(g_zero_base);
+        st_w = *sp; off_b = db[0]; row_b = (uint32_t)db[1];
+    }
     auto pre0 = [&]() {
         if (pair) {
             const float2 t = *reinterpret_cast<const float2*>(a.b + k0);
@@ -531,7 +542,7 @@ __device__ __forceinline__ void visible_body(const VisibleArgs& a, int ms, int n
     QBM_STAMP(12);
 }
 
-template <class TA, bool FAST, int CM, bool DB = false>
+template <class TA, bool FAST, int CM, bool XA = false>
 __global__ __launch_bounds__(64 * V_NQ) void k_visible(VisibleArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -539,11 +550,11 @@ __global__ __launch_bounds__(64 * V_NQ) void k_visible(VisibleArgs a)
     // aux workgroups in front of the strips (or none): the strips' part of the grid is padded so that the row strips that
     // read one block of W rows share an XCD for ANY number of visible strips (49 at V = 784: strip_coords_padded)
     const bool padded = a.n_aux == a.B || a.n_aux == 0;
-    {   // aux workgroups behind a fused launch that gave up: nothing to do (the strips test the word in front of their stores)
+    if constexpr (XA) {   // aux workgroups behind a fused launch that gave up: nothing to do (the strips test the word in front of their stores)
         const bool is_aux = a.n_aux == a.B ? (int)blockIdx.x < a.n_aux + a.n_fe : (int)blockIdx.x >= nMs * nNs;
         if (a.n_aux > 0 && is_aux && a.status && *a.status != 0u) return;
+        if (a.hg_round && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && *a.status == 0u) *a.hg_round = *a.hg_round + 1u;
     }
-    if (a.hg_round && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0 && *a.status == 0u) *a.hg_round = *a.hg_round + 1u;
     if (a.n_aux == a.B) {
         // aux workgroups dealt first: the class conditional of one row each, its classes dealt to the first 4 wavefronts --
         // the shortest path to y (a wavefront that has ended takes no part in the workgroup's barriers)
@@ -551,7 +562,10 @@ __global__ __launch_bounds__(64 * V_NQ) void k_visible(VisibleArgs a)
             if (threadIdx.x >= 256) return;
             uint64_t oy = a.offset_y;
             uint32_t r0 = a.row0;
-            if constexpr (DB) { oy += a.draw_base[0]; r0 += (uint32_t)a.draw_base[1]; }
+            if constexpr (XA) {
+                const unsigned long long* db = a.draw_base ? reinterpret_cast<const unsigned long long*>(a.draw_base) : g_zero_base;
+                oy += db[0]; r0 += (uint32_t)db[1];
+            }
             class_row<TA, CM>(a.h, a.U, a.cb, a.py, a.ys, (int)blockIdx.x, a.H, a.C, a.seed, oy, r0, reinterpret_cast<float*>(lds));
             return;
         }
@@ -570,7 +584,10 @@ __global__ __launch_bounds__(64 * V_NQ) void k_visible(VisibleArgs a)
         if (i < a.B) {
             uint64_t oy = a.offset_y;
             uint32_t r0 = a.row0;
-            if constexpr (DB) { oy += a.draw_base[0]; r0 += (uint32_t)a.draw_base[1]; }
+            if constexpr (XA) {
+                const unsigned long long* db = a.draw_base ? reinterpret_cast<const unsigned long long*>(a.draw_base) : g_zero_base;
+                oy += db[0]; r0 += (uint32_t)db[1];
+            }
             class_row_wave<TA, CM>(a.h, a.U, a.cb, a.py, a.ys, i, a.H, a.C, a.seed, oy, r0, (int)threadIdx.x & 63);
         }
         return;
@@ -584,7 +601,7 @@ __global__ __launch_bounds__(64 * V_NQ) void k_visible(VisibleArgs a)
     } else {
         strip_coords(nMs, nNs, ms, ns, 0);
     }
-    visible_body<TA, FAST, V_MT, V_NT, 0, DB>(a, ms, ns, lds);
+    visible_body<TA, FAST, V_MT, V_NT, 0, XA>(a, ms, ns, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1820,7 +1837,7 @@ int launch_hidden_t(const qbm_rbm_params* P, const void* v, const float* y, int 
     const int nM = hp.nM, nN = hp.nN;
 #define QBM_LAUNCH(F, MODE, CM)                                                                      \
     {                                                                                                \
-        if (MODE == 0 && a.draw_base) {                                                                                   \
+        if (MODE == 0 && (a.draw_base || a.status)) {                                                                     \
             if (int rc = set_lds(k_hidden<TA, F, 0, CM, true>, lds)) return rc;                                           \
             hipLaunchKernelGGL((k_hidden<TA, F, 0, CM, true>), dim3(nM * nN), dim3(64 * NQ), lds, st, a);                 \
         } else {                                                                                                          \
@@ -1877,7 +1894,7 @@ int launch_visible_t(const qbm_rbm_params* P, const void* h, int B, float* p_v, 
     a.fe_stage = a.n_fe > 0 && P->C < NQ && 1280 + (size_t)P->C * P->H * sizeof(float) <= lds;
 #define QBM_LAUNCH(F, CM)                                                                       \
     {                                                                                           \
-        if (a.draw_base) {                                                                            \
+        if (a.draw_base || a.status) {                                                                \
             if (int rc = set_lds(k_visible<TA, F, CM, true>, lds)) return rc;                         \
             hipLaunchKernelGGL((k_visible<TA, F, CM, true>), dim3(grid), dim3(64 * NQ), lds, st, a);  \
         } else {                                                                                      \
