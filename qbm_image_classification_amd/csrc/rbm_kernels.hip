@@ -266,9 +266,12 @@ __global__ __launch_bounds__(64 * H_NQ) void k_hidden(HiddenArgs a)
     // are first used, one dependent s_load latency after the other in front of the first operand transfer
     asm volatile("" ::"s"(a.v), "s"(a.y), "s"(a.W), "s"(a.d), "s"(a.U), "s"(a.p), "s"(a.s), "s"(a.s8), "s"(a.B), "s"(a.V),
                  "s"(a.H), "s"(a.C), "s"(a.KP), "s"(a.seed), "s"(a.offset), "s"(a.row0), "s"(a.pre));
-    const int nM = (a.B + 16 * H_MT - 1) / (16 * H_MT), nN = (a.H + 16 * H_NT - 1) / (16 * H_NT);
-    int ms, ns;
-    strip_coords(nM, nN, ms, ns);
+    // grid (8, nM, ceil(nN / 8)): workgroups are numbered x + 8 (y + nM z) and dealt to the XCDs round-robin, so XCD x takes the
+    // column strips x, x + 8, ... with all their row strips (the W panel of a column strip stays in one L2) -- and the
+    // coordinates come without the integer division a linear grid needs (~60 scalar instructions with a v_rcp round trip
+    // in front of the first operand request, on every wavefront)
+    const int ms = (int)blockIdx.y, ns = (int)blockIdx.x + 8 * (int)blockIdx.z;
+    if (ns * 16 * H_NT >= a.H) return;   // (padding of the last group of 8 column strips)
     hidden_body<TA, FASTK, MODE, CM, 0, NoPre, XA>(a, ms, ns, lds);
 }
 
@@ -462,6 +465,7 @@ struct VisibleArgs {
     // rows, one row each: -F, p(y|x0) and the row's two loss terms from x0.W + d (stored by the launch in front)
     int n_fe; const float* fe_pre; const int* fe_labels; float* fe_p; float* fe_rowloss;
     int fe_stage;             // the softplus terms of a monitor row staged through LDS (they fit behind the row's small arrays)
+    unsigned inv_nm;          // div_magic(row strips): the strips' coordinates without an integer division
     const uint64_t* draw_base;   // as HiddenArgs::draw_base (added to offset, offset_y and row0)
     uint32_t* hg_round;       // non-null: the fused tail of the step (k_hgrad) is the next launch: this one advances the word
                               // that launch takes its barrier round from (one writer, a kernel boundary in front of the readers:
@@ -597,9 +601,9 @@ __global__ __launch_bounds__(64 * V_NQ) void k_visible(VisibleArgs a)
                  "s"(a.seed), "s"(a.offset), "s"(a.row0));   // all arguments in one scalar-cache round trip (see k_hidden)
     int ms, ns;
     if (padded) {
-        if (!strip_coords_padded(nMs, nNs, ms, ns, a.n_aux + a.n_fe)) return;
+        if (!strip_coords_padded(nMs, nNs, ms, ns, a.n_aux + a.n_fe, a.inv_nm)) return;
     } else {
-        strip_coords(nMs, nNs, ms, ns, 0);
+        strip_coords(nMs, nNs, ms, ns, 0, a.inv_nm);
     }
     visible_body<TA, FAST, V_MT, V_NT, 0, XA>(a, ms, ns, lds);
 }
@@ -778,7 +782,7 @@ __global__ __launch_bounds__(512) void k_chain(ChainArgs a)
         } else {
             if (j < nNv) {
                 const VisibleArgs va{a.h, a.W, a.b, nullptr, nullptr, vout, a.B, a.V, a.H, a.KPv, a.seed, off - 2, a.row0, a.vecO,
-                                     a.U, a.c, nullptr, yout, a.C, off - 1, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
+                                     a.U, a.c, nullptr, yout, a.C, off - 1, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0u, nullptr, nullptr};
                 visible_body<uint8_t, true, 2, 2, kSc1>(va, g, j, lds + a.ldsT);
             }
             // class conditional of the block's 32 rows, one row per wavefront, on the workgroups that have no strip -- or,
@@ -975,6 +979,7 @@ struct GradArgs {
     int lds_group;                               // bytes of one group's LDS staging region
     int lds_group0;                              // k_hgrad: byte offset of the staging area of phase 0 (behind what the hidden phase uses)
     int lds_sok;                                 // k_hgrad: byte offset of the barrier's result word
+    unsigned inv_nm;                             // div_magic(row strips of W): strip coordinates without an integer division
     const uint32_t* status;                      // non-null: status word of the fused chain launch in front (sync[512]);
                                                  // non-zero = that launch gave up: this launch writes nothing (but n_rows)
     float* n_rows;                               // non-null: receives (float)B -- the data-parallel path all-reduces it with the
@@ -1371,7 +1376,7 @@ __global__ __launch_bounds__(PAR ? 512 : 256) void k_grad(GradArgs a)
         }
     }
     int ms, ns;
-    strip_coords(nM, nN, ms, ns, a.nU + a.nB + a.nC);
+    strip_coords(nM, nN, ms, ns, a.nU + a.nB + a.nC, a.inv_nm);
     const int m0 = ms * 16 * MT, n0 = ns * 16 * NT;
     using SO = StripOut<MT, NT>;
     if constexpr (PAR) {
@@ -1839,10 +1844,10 @@ int launch_hidden_t(const qbm_rbm_params* P, const void* v, const float* y, int 
     {                                                                                                \
         if (MODE == 0 && (a.draw_base || a.status)) {                                                                     \
             if (int rc = set_lds(k_hidden<TA, F, 0, CM, true>, lds)) return rc;                                           \
-            hipLaunchKernelGGL((k_hidden<TA, F, 0, CM, true>), dim3(nM * nN), dim3(64 * NQ), lds, st, a);                 \
+            hipLaunchKernelGGL((k_hidden<TA, F, 0, CM, true>), dim3(8, nM, (nN + 7) / 8), dim3(64 * NQ), lds, st, a);     \
         } else {                                                                                                          \
             if (int rc = set_lds(k_hidden<TA, F, MODE, CM>, lds)) return rc;                                              \
-            hipLaunchKernelGGL((k_hidden<TA, F, MODE, CM>), dim3(nM * nN), dim3(64 * NQ), lds, st, a);                    \
+            hipLaunchKernelGGL((k_hidden<TA, F, MODE, CM>), dim3(8, nM, (nN + 7) / 8), dim3(64 * NQ), lds, st, a);        \
         }                                                                                                                 \
     }
     if (mode != 0 || !y) {  // no class term: the class-count bucket is irrelevant
@@ -1880,7 +1885,7 @@ int launch_visible_t(const qbm_rbm_params* P, const void* h, int B, float* p_v, 
                   // pairs of visible units: 8-byte accesses to p / v_f32 / b, 2-byte accesses to v_u8
                   (P->V % 2 == 0) && (!p_v || aligned8(p_v)) && (!v_s || aligned8(v_s)) && (!v_s8 || aligned2(v_s8)) &&
                       aligned8(P->b),
-                  P->U, P->c, p_y, y1hot, P->C, offset_y, with_class ? (B <= 512 ? B : (B + NQ - 1) / NQ) : 0, status, 0, nullptr, nullptr, nullptr, nullptr, 0,
+                  P->U, P->c, p_y, y1hot, P->C, offset_y, with_class ? (B <= 512 ? B : (B + NQ - 1) / NQ) : 0, status, 0, nullptr, nullptr, nullptr, nullptr, 0, div_magic(nM),
                   draw_base, status ? hg_round : nullptr};
     if (mon && a.n_aux == B) {   // (visible_takes_monitor: the caller has asked)
         a.n_fe = B; a.fe_pre = mon->mon_pre; a.fe_labels = mon->mon_labels; a.fe_p = mon->mon_p; a.fe_rowloss = mon->mon_rowloss;
@@ -1946,7 +1951,7 @@ int launch_grad_t(int V, int H, int C, int B, const void* A0, const float* Y0, c
                aux_fused ? aux_fused->U : nullptr, aux_fused ? aux_fused->c : nullptr,
                lr, factor, bs, sparse, B, V, H, C, panel_for<MT, NT, 4>(B),
                nN, want_b ? nM : 0, want_c ? (C + 16 * NT - 1) / (16 * NT) : 0,
-               (H % 4 == 0) && (!G->gW || aligned16(G->gW)) && (!W_fused || aligned16(W_fused)), gU_sub, 0, 0, 0, status, G->n_rows,
+               (H % 4 == 0) && (!G->gW || aligned16(G->gW)) && (!W_fused || aligned16(W_fused)), gU_sub, 0, 0, 0, div_magic(nM), status, G->n_rows,
                0, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (mon_rowloss && mon_loss_acc) { a.nL = 1; a.rowloss = mon_rowloss; a.loss_acc = mon_loss_acc; }
     if (dx) {
@@ -2151,7 +2156,7 @@ int launch_hgrad(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void* v0
                 fuse_update ? P->b : nullptr, fuse_update ? P->d : nullptr, fuse_update ? P->U : nullptr,
                 fuse_update ? P->c : nullptr, lr, factor, bs, sparse, B, V, H, C, 64,
                 0, want_b ? 1 : 0, want_c ? 1 : 0,
-                (H % 4 == 0) && (!g.gW || aligned16(g.gW)) && aligned16(P->W), nullptr, 0, 0, 0, nullptr, G->n_rows,
+                (H % 4 == 0) && (!g.gW || aligned16(g.gW)) && aligned16(P->W), nullptr, 0, 0, 0, 0u, nullptr, G->n_rows,
                 0, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (mon_rowloss && mon_loss_acc) { ga.nL = 1; ga.rowloss = mon_rowloss; ga.loss_acc = mon_loss_acc; }
     // LDS.  Items that go in one call: a staging region per thread group, sized for the largest kind (see launch_grad_t).

@@ -43,7 +43,7 @@ namespace qbm { constexpr int kStampWaves = 8192; static __device__ unsigned lon
     do {                                                                                                      \
         unsigned long long t__;                                                                               \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                          \
-        const unsigned w__ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                             \
+        const unsigned w__ = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * (blockDim.x >> 6) + (threadIdx.x >> 6); \
         if ((threadIdx.x & 63) == 0 && w__ < (unsigned)qbm::kStampWaves) qbm::g_stamps[w__ * 16 + (i)] = t__; \
     } while (0)
 #endif
@@ -860,22 +860,27 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
 // The same for any nN, on a grid padded to 8 * nM * ceil(nN / 8) strips workgroups (strip_grid_padded): XCD x takes the n
 // strips x, x + 8, ... with all their m strips; false = a workgroup of the padding (nothing to do).
 __host__ __device__ __forceinline__ int strip_grid_padded(int nM, int nN) { return 8 * nM * ((nN + 7) / 8); }
-__device__ __forceinline__ bool strip_coords_padded(int nM, int nN, int& ms, int& ns, int first = 0)
+// j / d without the ~60-instruction integer division (a v_rcp round trip in front of a kernel's first operand request, on
+// every wavefront): inv = div_magic(d) = ceil(2^32 / d) from the host, exact for j < 2^32 / d; inv == 0 (d == 1, or a caller
+// that passes none): the plain division
+inline unsigned div_magic(int d) { return d >= 2 ? (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d) : 0u; }
+__device__ __forceinline__ int div_by(int j, int d, unsigned inv) { return inv ? (int)__umulhi((unsigned)j, inv) : j / d; }
+__device__ __forceinline__ bool strip_coords_padded(int nM, int nN, int& ms, int& ns, int first = 0, unsigned inv_nM = 0u)
 {
     const int id = (int)blockIdx.x - first;
-    const int x = id & 7, j = id >> 3;
-    ns = x + 8 * (j / nM);
-    ms = j % nM;
+    const int x = id & 7, j = id >> 3, q = div_by(j, nM, inv_nM);
+    ns = x + 8 * q;
+    ms = j - q * nM;
     return ns < nN;
 }
 
-__device__ __forceinline__ void strip_coords(int nM, int nN, int& ms, int& ns, int first = 0)
+__device__ __forceinline__ void strip_coords(int nM, int nN, int& ms, int& ns, int first = 0, unsigned inv_nM = 0u)
 {
     const int id = (int)blockIdx.x - first;  // `first` aux workgroups precede the strips in the grid
     if ((nN & 7) == 0) {
-        const int x = id & 7, j = id >> 3;
-        ns = x + 8 * (j / nM);
-        ms = j % nM;
+        const int x = id & 7, j = id >> 3, q = div_by(j, nM, inv_nM);
+        ns = x + 8 * q;
+        ms = j - q * nM;
     } else {
         ms = id / nN;
         ns = id % nN;
