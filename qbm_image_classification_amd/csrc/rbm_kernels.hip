@@ -1303,7 +1303,8 @@ __global__ __launch_bounds__(PAR ? 512 : 256) void k_grad(GradArgs a)
     extern __shared__ __attribute__((aligned(16))) char lds_all[];
     QBM_STAMP(10);
     asm volatile("" ::"s"(a.A0), "s"(a.P0), "s"(a.A1), "s"(a.P1), "s"(a.gW), "s"(a.W), "s"(a.B), "s"(a.V), "s"(a.H), "s"(a.C),
-                 "s"(a.KP), "s"(a.nU), "s"(a.nB), "s"(a.nC), "s"(a.lds_group));   // the arguments of the W workgroups in one scalar-cache round trip
+                 "s"(a.KP), "s"(a.nU), "s"(a.nB), "s"(a.nC), "s"(a.lds_group), "s"(a.nL), "s"(a.nD), "s"(a.inv_nm), "s"(a.status),
+                 "s"(a.n_rows));   // the arguments of the W workgroups in one scalar-cache round trip
     const int grp = PAR ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;   // 0: phase-0 operands, 1: phase-1 operands
     char* lds = lds_all + (size_t)grp * a.lds_group;
     int blk = blockIdx.x;
