@@ -350,7 +350,10 @@ class ClassificationRBM:
                             else:
                                 self.contrastive_divergence_training(batch, labels, gen_factor, onehot=onehot, loss_acc=sums,
                                                                      _rel=(i, self._draw_base))
-                    epoch_graph = self._epoch_graph = (key, g)
+                    # (the graph's launches hold the addresses of the step's scratch: the workspaces of the moment are kept alive with
+                    # it, whatever the ops object's caches evict later)
+                    keep = (dict(getattr(self.ops, '_cd_wss', {})), dict(getattr(self.ops, '_disc_wss', {})), views, sums, self._draw_base)
+                    epoch_graph = self._epoch_graph = (key, g, keep)
                 if method == 'generative':   # this epoch's base of the draw ids / Philox rows, then the host counters move on
                     self._draw_base.copy_(torch.tensor([self._draw_offset, self._rows_seen & 0xFFFFFFFF], dtype=torch.int64))
                     self._draw_offset += len(views) * (3 * self.k + 1)
