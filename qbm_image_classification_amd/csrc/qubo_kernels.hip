@@ -169,17 +169,19 @@ __device__ __forceinline__ void gibbs_chain(const float* __restrict__ lin, const
         for (int t = 0; t < NF; ++t) {
             const int cnt = min(64, n - 64 * t);   // <= 0: a tile beyond n (no spin to visit: `pending` is empty)
             unsigned long long pending = (cnt >= 64) ? ~0ull : (cnt <= 0 ? 0ull : ((1ull << cnt) - 1ull));  // spins of this tile not yet visited
-            while (pending) {
-                const bool ns = (beta * F[t]) < thr[t];
-                const unsigned long long want = (__ballot(ns) ^ sm[t]) & pending;
-                if (want == 0ull) break;
+            // (rotated: one test per iteration, at the bottom; an empty `pending` gives an empty `want`)
+            unsigned long long want = (__ballot((beta * F[t]) < thr[t]) ^ sm[t]) & pending;
+            while (want) {
                 const int l = __builtin_ctzll(want);              // first spin that flips; the ones before it stay
-                const float sg = ((sm[t] >> l) & 1ull) ? -1.0f : 1.0f;
+                // +-1 by the spin's state before the flip: one scalar bit test and select
+                float sg;
+                asm("s_bitcmp1_b64 %1, %2\n\ts_cselect_b32 %0, 0xbf800000, 0x3f800000" : "=s"(sg) : "s"(sm[t]), "s"(l) : "scc");
                 row_of_tile<NF>(jr, t, 64 * t + l, lane, jrow);
 #pragma unroll
                 for (int tt = 0; tt < NF; ++tt) F[tt] = __builtin_fmaf(sg, jrow[tt], F[tt]);
                 sm[t] ^= 1ull << l;
                 pending &= (~0ull << l) << 1;                      // the spins behind l
+                want = (__ballot((beta * F[t]) < thr[t]) ^ sm[t]) & pending;
             }
         }
     }
