@@ -270,8 +270,10 @@ __global__ __launch_bounds__(64 * H_NQ) void k_hidden(HiddenArgs a)
     // column strips x, x + 8, ... with all their row strips (the W panel of a column strip stays in one L2) -- and the
     // coordinates come without the integer division a linear grid needs (~60 scalar instructions with a v_rcp round trip
     // in front of the first operand request, on every wavefront)
-    const int ms = (int)blockIdx.y, ns = (int)blockIdx.x + 8 * (int)blockIdx.z;
-    if (ns * 16 * H_NT >= a.H) return;   // (padding of the last group of 8 column strips)
+    // ... in PAIRS (strips 2j, 2j + 1 on XCD j % 8): the gradient launch's column strips are 32 wide and dealt the same way,
+    // so it finds p(h) -- and the next step's first launch the W columns the gradient launch has just updated -- in its XCD's L2
+    const int ms = (int)blockIdx.y, ns = 16 * ((int)blockIdx.z >> 1) + 2 * (int)blockIdx.x + ((int)blockIdx.z & 1);
+    if (ns * 16 * H_NT >= a.H) return;   // (padding of the last group of 16 column strips)
     hidden_body<TA, FASTK, MODE, CM, 0, NoPre, XA>(a, ms, ns, lds);
 }
 
@@ -1377,7 +1379,7 @@ __global__ __launch_bounds__(PAR ? 512 : 256) void k_grad(GradArgs a)
         }
     }
     int ms, ns;
-    strip_coords(nM, nN, ms, ns, a.nU + a.nB + a.nC, a.inv_nm);
+    strip_coords<true>(nM, nN, ms, ns, a.nU + a.nB + a.nC, a.inv_nm);
     const int m0 = ms * 16 * MT, n0 = ns * 16 * NT;
     using SO = StripOut<MT, NT>;
     if constexpr (PAR) {
@@ -1845,10 +1847,10 @@ int launch_hidden_t(const qbm_rbm_params* P, const void* v, const float* y, int 
     {                                                                                                \
         if (MODE == 0 && (a.draw_base || a.status)) {                                                                     \
             if (int rc = set_lds(k_hidden<TA, F, 0, CM, true>, lds)) return rc;                                           \
-            hipLaunchKernelGGL((k_hidden<TA, F, 0, CM, true>), dim3(8, nM, (nN + 7) / 8), dim3(64 * NQ), lds, st, a);     \
+            hipLaunchKernelGGL((k_hidden<TA, F, 0, CM, true>), dim3(8, nM, 2 * ((nN + 15) / 16)), dim3(64 * NQ), lds, st, a);     \
         } else {                                                                                                          \
             if (int rc = set_lds(k_hidden<TA, F, MODE, CM>, lds)) return rc;                                              \
-            hipLaunchKernelGGL((k_hidden<TA, F, MODE, CM>), dim3(8, nM, (nN + 7) / 8), dim3(64 * NQ), lds, st, a);        \
+            hipLaunchKernelGGL((k_hidden<TA, F, MODE, CM>), dim3(8, nM, 2 * ((nN + 15) / 16)), dim3(64 * NQ), lds, st, a);        \
         }                                                                                                                 \
     }
     if (mode != 0 || !y) {  // no class term: the class-count bucket is irrelevant

@@ -17,6 +17,32 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
+def conv_lines(a):
+    """HipGibbsSampler.sample_Q (src/qubo/sampler.py:26-33) on the committed conv-QBM QUBOs: ONE QUBO per call, `reads`
+    chains, host arrays in and out -- what src/train/pipeline.py would ask of it."""
+    import time
+
+    from qbm_image_classification_amd.sampler import HipGibbsSampler
+
+    d = np.load(os.path.join(ROOT, "tests", "golden", "cdqbm_qubo.npz"))
+    for key in ("Q_clamped", "Q_unclamped"):
+        Q = d[key][0].astype(np.float64)
+        n = Q.shape[0]
+        for sweeps in a.sweeps:
+            smp = HipGibbsSampler(num_sweeps=sweeps, seed=7)
+            smp.sample_Q(Q, a.reads)
+            best = float("inf")
+            for _ in range(a.reps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                s = smp.sample_Q(Q, a.reads)
+                best = min(best, time.perf_counter() - t0)
+            e = np.einsum("ri,ij,rj->r", s.astype(np.float64), Q, s.astype(np.float64))
+            print(json.dumps({"what": f"sample_Q, conv-QBM {key} n = {n} ({int((Q != 0).sum())} non-zeros), {a.reads} reads, {sweeps} sweeps, host call",
+                              "ms_per_call": round(best * 1e3, 3), "spin_updates_per_s": round(a.reads * sweeps * n / best, 1),
+                              "energy_min": round(float(e.min()), 4), "energy_mean": round(float(e.mean()), 4)}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sweeps", type=int, nargs="+", default=[100, 1000])
@@ -24,7 +50,10 @@ def main():
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--images", type=int, default=73)
     ap.add_argument("--reads", type=int, default=100)
+    ap.add_argument("--conv", action="store_true", help="sample_Q on the conv-QBM QUBOs of tests/golden/cdqbm_qubo.npz (n = 716 / 717) instead")
     a = ap.parse_args()
+    if a.conv:
+        return conv_lines(a)
     from qbm_image_classification_amd.disc_qbm import Disc_QBM
 
     rs = np.random.RandomState(0)
