@@ -106,6 +106,7 @@ struct HiddenArgs {
                               // workspace keeps what the host needs to finish that step: k_hgrad)
     const uint64_t* draw_base;   // non-null: [2] device words added to (offset, row0) -- qbm_rbm_cd_workspace.draw_base: the
                                  // launches of an epoch captured in a hipGraph keep their arguments, the counters move on
+    int pair;        // k_hidden's grid: column strips 2j, 2j + 1 on XCD j % 8 (H a multiple of 256) instead of strip c on XCD c % 8
 };
 
 // 8 wavefronts (512 threads): wavefront q contracts chain q of the 8 the K = V terms are cut into ([Q] with NQ = 8), two
@@ -265,15 +266,18 @@ __global__ __launch_bounds__(64 * H_NQ) void k_hidden(HiddenArgs a)
     // every kernel argument in ONE round trip to the (cold) scalar cache: the compiler otherwise fetches them where they
     // are first used, one dependent s_load latency after the other in front of the first operand transfer
     asm volatile("" ::"s"(a.v), "s"(a.y), "s"(a.W), "s"(a.d), "s"(a.U), "s"(a.p), "s"(a.s), "s"(a.s8), "s"(a.B), "s"(a.V),
-                 "s"(a.H), "s"(a.C), "s"(a.KP), "s"(a.seed), "s"(a.offset), "s"(a.row0), "s"(a.pre));
+                 "s"(a.H), "s"(a.C), "s"(a.KP), "s"(a.seed), "s"(a.offset), "s"(a.row0), "s"(a.pre), "s"(a.pair));
     // grid (8, nM, ceil(nN / 8)): workgroups are numbered x + 8 (y + nM z) and dealt to the XCDs round-robin, so XCD x takes the
     // column strips x, x + 8, ... with all their row strips (the W panel of a column strip stays in one L2) -- and the
     // coordinates come without the integer division a linear grid needs (~60 scalar instructions with a v_rcp round trip
     // in front of the first operand request, on every wavefront)
-    // ... in PAIRS (strips 2j, 2j + 1 on XCD j % 8): the gradient launch's column strips are 32 wide and dealt the same way,
-    // so it finds p(h) -- and the next step's first launch the W columns the gradient launch has just updated -- in its XCD's L2
-    const int ms = (int)blockIdx.y, ns = 16 * ((int)blockIdx.z >> 1) + 2 * (int)blockIdx.x + ((int)blockIdx.z & 1);
-    if (ns * 16 * H_NT >= a.H) return;   // (padding of the last group of 16 column strips)
+    // a.pair (H a multiple of 256): in PAIRS, strips 2j, 2j + 1 on XCD j % 8 -- the gradient launch deals its column strips
+    // (32 wide, or 16 wide in the same pairs) the same way, so it finds p(h), and the next step's first launch the W columns
+    // the gradient launch has just updated, in its XCD's L2, which keeps its lines over a kernel boundary (CD-1 at 784 x 512,
+    // B = 256: 29.5 -> 28.4 us per step; tools/step_timeline.py)
+    const int bx = (int)blockIdx.x, bz = (int)blockIdx.z;
+    const int ms = (int)blockIdx.y, ns = a.pair ? 16 * (bz >> 1) + 2 * bx + (bz & 1) : bx + 8 * bz;
+    if (ns * 16 * H_NT >= a.H) return;   // (padding of the last group of 8 column strips)
     hidden_body<TA, FASTK, MODE, CM, 0, NoPre, XA>(a, ms, ns, lds);
 }
 
@@ -1379,7 +1383,7 @@ __global__ __launch_bounds__(PAR ? 512 : 256) void k_grad(GradArgs a)
         }
     }
     int ms, ns;
-    strip_coords<true>(nM, nN, ms, ns, a.nU + a.nB + a.nC, a.inv_nm);
+    strip_coords<true>(nM, nN, ms, ns, a.nU + a.nB + a.nC, a.inv_nm, NT == 1 && (nN & 15) == 0);   // (k_hidden's pairs: H % 256 == 0)
     const int m0 = ms * 16 * MT, n0 = ns * 16 * NT;
     using SO = StripOut<MT, NT>;
     if constexpr (PAR) {
@@ -1809,6 +1813,7 @@ HiddenPlan plan_hidden(const qbm_rbm_params* P, const void* v, const float* y, i
     const bool fast = (P->V % 16 == 0) && aligned16(v) && (P->H % 4 == 0) && aligned16(P->W) &&
                       small2g((long)B * P->V, ASZ) && small2g((long)P->V * P->H, 4);
     const int nM = (B + 16 * MT - 1) / (16 * MT), nN = (P->H + 16 * NT - 1) / (16 * NT);
+    a.pair = (nN % 16 == 0) ? 1 : 0;
     // More strips than CUs (B > 256 at H = 512): panels of 64 k, i.e. 56 KB of LDS instead of 104 KB, so that TWO workgroups
     // share a CU and one's transfers run under the other's MFMAs (784x512, uint8 states: B = 512 / 1024 / 2048 / 4096:
     // 48 / 83 / 141 / 262 us per CD-1 step against 51 / 92 / 161 / 306 with whole-chain panels; at B = 256, one workgroup
@@ -1847,10 +1852,10 @@ int launch_hidden_t(const qbm_rbm_params* P, const void* v, const float* y, int 
     {                                                                                                \
         if (MODE == 0 && (a.draw_base || a.status)) {                                                                     \
             if (int rc = set_lds(k_hidden<TA, F, 0, CM, true>, lds)) return rc;                                           \
-            hipLaunchKernelGGL((k_hidden<TA, F, 0, CM, true>), dim3(8, nM, 2 * ((nN + 15) / 16)), dim3(64 * NQ), lds, st, a);     \
+            hipLaunchKernelGGL((k_hidden<TA, F, 0, CM, true>), dim3(8, nM, (nN + 7) / 8), dim3(64 * NQ), lds, st, a);     \
         } else {                                                                                                          \
             if (int rc = set_lds(k_hidden<TA, F, MODE, CM>, lds)) return rc;                                              \
-            hipLaunchKernelGGL((k_hidden<TA, F, MODE, CM>), dim3(8, nM, 2 * ((nN + 15) / 16)), dim3(64 * NQ), lds, st, a);        \
+            hipLaunchKernelGGL((k_hidden<TA, F, MODE, CM>), dim3(8, nM, (nN + 7) / 8), dim3(64 * NQ), lds, st, a);        \
         }                                                                                                                 \
     }
     if (mode != 0 || !y) {  // no class term: the class-count bucket is irrelevant

@@ -876,13 +876,14 @@ __device__ __forceinline__ bool strip_coords_padded(int nM, int nN, int& ms, int
 
 // ABS: n strip ns goes to XCD ns % 8 whatever `first` is (a rotation inside every group of 8 workgroups): a launch whose n
 // strips cover what the n strips of the launch before it wrote finds that in its XCD's L2 (k_grad behind k_hidden)
+// pair (nN a multiple of 16): n strips 2j, 2j + 1 on XCD j % 8 instead (k_hidden's map when H is a multiple of 256)
 template <bool ABS = false>
-__device__ __forceinline__ void strip_coords(int nM, int nN, int& ms, int& ns, int first = 0, unsigned inv_nM = 0u)
+__device__ __forceinline__ void strip_coords(int nM, int nN, int& ms, int& ns, int first = 0, unsigned inv_nM = 0u, bool pair = false)
 {
     const int id = (int)blockIdx.x - first;  // `first` aux workgroups precede the strips in the grid
     if ((nN & 7) == 0) {
         const int x = (ABS ? (int)blockIdx.x : id) & 7, j = id >> 3, q = div_by(j, nM, inv_nM);
-        ns = x + 8 * q;
+        ns = pair ? 16 * (q >> 1) + 2 * x + (q & 1) : x + 8 * q;
         ms = j - q * nM;
     } else {
         ms = id / nN;
