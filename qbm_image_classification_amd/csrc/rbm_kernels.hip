@@ -1687,7 +1687,13 @@ __global__ __launch_bounds__(256) void k_update(UpdateArgs a)
         a.bs = *a.bs_dev;
         if (!(a.bs > 0.f) || a.bs > 3.0e38f) return;
     }
-    for (long i = a.first + (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    // Which workgroup takes which 128-byte line (a speed-only permutation inside every 8 workgroups x 8 lines): workgroup b sits
+    // on XCD b % 8 and takes the lines l = b % 8 (mod 8) -- with H a multiple of 32 that is W's 32-column blocks j = b % 8 (mod 8),
+    // the ones k_hidden's workgroups on that XCD read next (the fused update inside k_grad has the same owner)
+    const bool perm = (gridDim.x & 7) == 0 && blockDim.x == 256;
+    const int t = (int)threadIdx.x, bx = (int)blockIdx.x;
+    const long id0 = perm ? (((long)(bx >> 3) * 64 + 8 * (t >> 5) + (bx & 7)) * 32 + (t & 31)) : (long)bx * blockDim.x + t;
+    for (long i = a.first + id0; i < total; i += (long)gridDim.x * blockDim.x) {
         float* th; const float* g; long k = i; bool sp = false;
         if (k < nW) { th = a.W; g = a.gW; }
         else if ((k -= nW) < a.V) { th = a.b; g = a.gb; sp = true; }
@@ -2332,7 +2338,7 @@ int qbm_rbm_update_dev(const qbm_rbm_params* P, const qbm_rbm_grads* G, float lr
     UpdateArgs a{P->W, P->b, P->d, P->U, P->c, G->gW, G->gb, G->gd, G->gU, G->gc, P->V, P->H, P->C,
                  lr, factor, batch_size, sparse_constant, G->gW ? 0 : nW, batch_size_dev, chain_status};
     const long n = total - a.first;
-    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    const int blocks = (int)(((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048) + 7) / 8 * 8;   // whole groups of 8: k_update's line map
     hipLaunchKernelGGL(k_update, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     QBM_CHECK_LAUNCH("k_update");
     return QBM_OK;
