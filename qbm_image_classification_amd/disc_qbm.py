@@ -335,6 +335,42 @@ class Disc_QBM:
         w_hh = None if self.restricted else np.zeros(self.weights_hidden_hidden.shape)   # never filled (:831-845)
         return (b_h.cpu().numpy(), b_o.cpu().numpy(), W_vh.cpu().numpy(), W_vo.cpu().numpy().reshape(-1, 1), w_oo, w_hh)
 
+    def get_average_configuration(self, samples, input_vector, label=None):
+        """src/model/faster_dqbm.py:688-752, the statistics of ONE image from its list of sample dicts (host arithmetic: the
+        training step uses the batched form below) -> (b_h, b_o, W_vh, W_vo, W_oo, W_hh).  Unlike the batched form this one
+        does fill W_hh (upper triangle of the read-averaged products, :739-748) and keeps the reference's row order of W_vh
+        (rows 0..D-1 = x, row D = the label when clamped: :712-724)."""
+        no, H, D = self.n_output_nodes, self.n_hidden_nodes, self.dim_input
+        S = np.vstack([np.array(list(s.values())) for s in samples]).astype(np.float64)          # [R, n]
+        unclamped = label is None
+        lab = None if unclamped else np.array(label).flatten()
+        avg = np.average(S, axis=0)
+        hid = S[:, no:] if unclamped else S
+        b_h = avg[no:] if unclamped else avg
+        b_o = avg[:no] if unclamped else lab
+        x = np.asarray(input_vector, dtype=np.float64).reshape(-1)
+        vis = x if unclamped else np.concatenate((x, lab))
+        w_vh = np.zeros(self.weights_all_visible_to_hidden.shape)
+        # np.average(x_v * samples[:, h]) entry by entry (:719-724): the product first, then the mean over the reads
+        w_vh[:vis.shape[0], :] = np.average(vis[None, :, None] * hid[:, None, :], axis=0)
+        w_vo = np.zeros(self.weights_clamped_visible_to_output.shape)
+        out = S[:, :no] if unclamped else np.broadcast_to(lab.astype(np.float64), (1, no))
+        w_vo[:D, :] = np.average(x[None, :, None] * out[:, None, :], axis=0)
+        w_oo = np.zeros(self.weights_output_output.shape)
+        for o in range(no):
+            for o2 in range(o + 1, no):
+                w_oo[o, o2] = np.average(S[:, o] * S[:, o2]) if unclamped else np.average(lab[o] * lab[o2])
+        w_hh = None
+        if not self.restricted:
+            w_hh = np.triu(np.average(hid[:, :, None] * hid[:, None, :], axis=0), k=1)
+        return b_h, b_o, w_vh, w_vo, w_oo, w_hh
+
+    def get_best_combined_acc_auc(self):
+        """src/model/faster_dqbm.py:1334-1339 -> (best epoch, its accuracy, its AUC, 0.5 acc + 0.5 AUC)"""
+        h = self.training_history
+        best = int(np.argmax(h.combined_acc_auc_per_epoch))
+        return best, h.acc_per_epoch[best], h.auc_per_epoch[best], h.combined_acc_auc_per_epoch[best]
+
     def get_average_configuration_batch(self, samples_batch, x_batch, y_batch=None):
         """src/model/faster_dqbm.py:754-848 -> (b_h, b_o, W_vh, W_vo, W_oo, W_hh) statistics.
         samples_batch: the reference's list[list[dict]] OR a float64 [B,n] tensor of per-image means."""

@@ -170,3 +170,35 @@ def test_assigning_w_hh_or_beta_eff_drops_the_derived_caches():
     q._J_cache = {True: "stale"}
     q.beta_eff = 2.0
     assert q._J_cache == {} and q.beta_eff == 2.0
+
+
+def test_single_image_statistics_sum_to_the_reference_batch_statistics():
+    """get_average_configuration (src/model/faster_dqbm.py:688-752) has no golden of its own; the batched form the golden
+    holds (:754-848) is its sum over the images for every block but W_hh (which only the single-image form fills: :739-748,
+    checked here against the definition, entry by entry)."""
+    g = golden("qbm_small.npz")
+    q = make(g, ops=OracleQuboOps({}))
+    X, Y = g["X"], g["Y"]
+    for tag, S, labels in (("clamped", g["S_clamped"], Y), ("unclamped", g["S_unclamped"], None)):
+        tot = None
+        for i in range(len(X)):
+            samples = [dict(enumerate(map(float, S[i, r]))) for r in range(S.shape[1])]
+            out = q.get_average_configuration(samples, X[i], None if labels is None else [labels[i]])
+            hid = S[i][:, 1:] if labels is None else S[i]
+            for h1 in range(hid.shape[1]):
+                for h2 in range(hid.shape[1]):
+                    want = np.average(hid[:, h1] * hid[:, h2]) if h2 > h1 else 0.0
+                    assert out[5][h1, h2] == pytest.approx(want, abs=1e-15)
+            part = [np.asarray(a, dtype=np.float64) for a in out[:5]]
+            tot = part if tot is None else [t + a for t, a in zip(tot, part)]
+        for nme, arr in zip(["b_h", "b_o", "W_vh", "W_vo", "W_oo"], tot):
+            assert np.max(np.abs(arr.reshape(g[f"avg_{tag}_{nme}"].shape) - g[f"avg_{tag}_{nme}"])) <= 1e-12, (tag, nme)
+
+
+def test_best_epoch_by_combined_accuracy_and_auc():
+    g = golden("qbm_small.npz")
+    q = make(g, ops=OracleQuboOps({}))
+    q.training_history.acc_per_epoch.extend([0.5, 0.8, 0.7])
+    q.training_history.auc_per_epoch.extend([0.5, 0.6, 0.9])
+    q.training_history.combined_acc_auc_per_epoch.extend([0.5, 0.7, 0.8])
+    assert q.get_best_combined_acc_auc() == (2, 0.7, 0.9, 0.8)
