@@ -33,6 +33,7 @@ namespace {
 // row<T>(p, ...): the row of spin p, which lies in tile T (compile-time in the unrolled sweep).  Lanes beyond n
 // ("phantom" spins of the last tile) get some finite value: their fields are never tested, flipped or stored.
 struct JGlobal {
+    static constexpr bool kExactTiles = false;   // instantiated for NF >= ceil(n / 64): a tile other than the last may be partial
     const float* J;
     int n;
     __device__ __forceinline__ void setup(int) {}
@@ -47,6 +48,7 @@ struct JGlobal {
 
 template <int NFT>
 struct JTri {
+    static constexpr bool kExactTiles = true;    // NFT == ceil(n / 64): every tile but the last holds 64 spins
     const float* tri;   // LDS
     int n;
     int ci[NFT];        // BYTE offset of S(i) - i for this lane's spins: T(i, p) at tri + ci + 4 p for i < p
@@ -63,9 +65,11 @@ struct JTri {
     template <int T, int NF>
     __device__ __forceinline__ void row(int p, int lane, float (&out)[NF]) const
     {
-        // wave-uniform (scalar unit): T(p, i) at tri + up + 4 i for i >= p; one vector add per tile in front of its read
-        // 4 (p n - p (p - 1) / 2 - p) = 2 p (2 n - 1 - p): three scalar instructions
-        const int up = 2 * p * (2 * n - 1 - p), p4 = 4 * p;
+        // wave-uniform: T(p, i) at tri + up + 4 i for i >= p; one vector add per tile in front of its read.
+        // up = 4 (p n - p (p - 1) / 2 - p) = 2 p (2 n - 1 - p) is what lane p % 64 holds as ci[T]: ONE v_readlane instead of
+        // four scalar instructions -- the flip loop is bound by the SIMD's scalar issue slot (one per 4 cycles, shared by its
+        // 3.75 wavefronts), not by latency: two chains in lockstep in one wavefront were 18 % SLOWER
+        const int up = __builtin_amdgcn_readlane(ci[T], p & 63), p4 = 4 * p;
         const char* base = reinterpret_cast<const char*>(tri);
 #pragma unroll
         for (int tt = 0; tt < NF; ++tt) {
@@ -170,6 +174,8 @@ __device__ __forceinline__ void gibbs_chain(const float* __restrict__ lin, const
             const int cnt = min(64, n - 64 * t);   // <= 0: a tile beyond n (no spin to visit: `pending` is empty)
             unsigned long long pending = (cnt >= 64) ? ~0ull : (cnt <= 0 ? 0ull : ((1ull << cnt) - 1ull));  // spins of this tile not yet visited
             // (rotated: one test per iteration, at the bottom; an empty `pending` gives an empty `want`)
+            // (the LDS reader's tiles are full but for the last: the spins behind l are -2 << l, no running mask)
+            const bool full = JR::kExactTiles && t + 1 < NF;
             unsigned long long want = (__ballot((beta * F[t]) < thr[t]) ^ sm[t]) & pending;
             while (want) {
                 const int l = __builtin_ctzll(want);              // first spin that flips; the ones before it stay
@@ -180,8 +186,12 @@ __device__ __forceinline__ void gibbs_chain(const float* __restrict__ lin, const
 #pragma unroll
                 for (int tt = 0; tt < NF; ++tt) F[tt] = __builtin_fmaf(sg, jrow[tt], F[tt]);
                 sm[t] ^= 1ull << l;
-                pending &= (~0ull << l) << 1;                      // the spins behind l
-                want = (__ballot((beta * F[t]) < thr[t]) ^ sm[t]) & pending;
+                if (full) {
+                    want = (__ballot((beta * F[t]) < thr[t]) ^ sm[t]) & ((~0ull << l) << 1);   // the spins behind l
+                } else {
+                    pending &= (~0ull << l) << 1;
+                    want = (__ballot((beta * F[t]) < thr[t]) ^ sm[t]) & pending;
+                }
             }
         }
     }
