@@ -292,10 +292,11 @@ __global__ __launch_bounds__(64 * H_NQ) void k_hidden(HiddenArgs a)
 // the team's thread 0 normalises and draws.  A workgroup barrier stands between the two (class_row = both, for a
 // 256-thread team that is alone in its workgroup).  `active` = false: the team has no row in this round (it only keeps
 // the workgroup's barrier count).
-template <class TH, int CM, bool SC1 = false>
+// under: called once by every wavefront while the loads of its first trip are in flight (class_row: the row's uniform)
+template <class TH, int CM, bool SC1 = false, class Under = NoPre>
 __device__ __forceinline__ void class_row_energies(const void* __restrict__ h, const float* __restrict__ U,
                                                    const float* __restrict__ cb, int i, int H, int C, int tid,
-                                                   float* __restrict__ e_s)
+                                                   float* __restrict__ e_s, Under&& under = NoPre{})
 {
     constexpr int CW = (CM + 3) / 4;   // classes per wave
     const int lane = tid & 63;
@@ -316,6 +317,7 @@ __device__ __forceinline__ void class_row_energies(const void* __restrict__ h, c
 #pragma unroll
             for (int c = 0; c < CW; ++c) uv[t][c] = U[(long)min(w + 4 * c, C - 1) * H + jj];
         }
+        if (jb == 0) under();
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -420,9 +422,39 @@ __device__ __forceinline__ void class_row(const void* __restrict__ h, const floa
                                           float* __restrict__ y_out, int i, int H, int C, uint64_t seed,
                                           uint64_t offset, uint32_t row0, float* __restrict__ e_s)
 {
-    class_row_energies<TH, CM>(h, U, cb, i, H, C, (int)threadIdx.x, e_s);
+    // The row's uniform is drawn by the last wavefront UNDER its first loads and parked behind the energies; the tail is then
+    // one wavefront's: lane c divides class c (one division in parallel instead of C in a row on one lane), every lane forms
+    // the running sum in class order from the lanes' quotients -- the same operations on the same values as class_row_draw
+    // (which the 8-rows-per-workgroup form keeps), a third of its instructions on the path to y.
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+    auto under = [&]() {
+        if (w == 3) {
+            const float u = uniform4(seed, offset, row0 + (uint32_t)i, 0u)[0];
+            if (lane == 0) e_s[QBM_MAX_CLASSES] = u;
+        }
+    };
+    class_row_energies<TH, CM>(h, U, cb, i, H, C, (int)threadIdx.x, e_s, under);
     __syncthreads();
-    if (threadIdx.x == 0) class_row_draw<CM>(p_out, y_out, i, C, seed, offset, row0, e_s);
+    if (w != 0) return;
+    float denom = 0.f;
+#pragma unroll
+    for (int c = 0; c < CM; ++c)
+        if (c < C) denom = denom + __builtin_fabsf(e_s[c]);
+    if (!(denom > 1e-12f)) denom = 1e-12f;
+    const float u = e_s[QBM_MAX_CLASSES];
+    const float p = e_s[min(lane, C - 1)] / denom;
+    if (p_out && lane < C) p_out[(long)i * C + lane] = p;
+    float cum = 0.f;
+    int pick = C - 1;
+    bool done = false;
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+        if (c < C) {
+            cum = cum + __shfl(p, c, kWave);
+            if (!done && u < cum) { pick = c; done = true; }
+        }
+    }
+    if (y_out && lane < C) y_out[(long)i * C + lane] = (lane == pick) ? 1.f : 0.f;
 }
 
 template <class TH, int CM>
