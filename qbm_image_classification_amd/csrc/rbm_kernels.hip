@@ -293,7 +293,8 @@ __global__ __launch_bounds__(64 * H_NQ) void k_hidden(HiddenArgs a)
 // 256-thread team that is alone in its workgroup).  `active` = false: the team has no row in this round (it only keeps
 // the workgroup's barrier count).
 // under: called once by every wavefront while the loads of its first trip are in flight (class_row: the row's uniform)
-template <class TH, int CM, bool SC1 = false, class Under = NoPre>
+// TR: columns per lane and trip (8: a row of up to 512 hidden units is ONE round of loads, not two one after the other)
+template <class TH, int CM, bool SC1 = false, class Under = NoPre, int TR = 4>
 __device__ __forceinline__ void class_row_energies(const void* __restrict__ h, const float* __restrict__ U,
                                                    const float* __restrict__ cb, int i, int H, int C, int tid,
                                                    float* __restrict__ e_s, Under&& under = NoPre{})
@@ -304,12 +305,12 @@ __device__ __forceinline__ void class_row_energies(const void* __restrict__ h, c
     float e[CW], cbv[CW];
 #pragma unroll
     for (int t = 0; t < CW; ++t) { e[t] = 0.f; cbv[t] = cb[min(w + 4 * t, C - 1)]; }
-    // per class the lane chains j = lane, lane+64, ... ascending ([T]).  256 columns per trip: all
-    // 4 + 4*CW loads of a trip are unconditional (index clamped, h masked to 0: fmaf(0, u, e) == e)
-    for (int jb = 0; jb < H; jb += 4 * kWave) {
-        float hv[4], uv[4][CW];
+    // per class the lane chains j = lane, lane+64, ... ascending ([T]).  64 TR columns per trip: all
+    // TR + TR*CW loads of a trip are unconditional (index clamped, h masked to 0: fmaf(0, u, e) == e)
+    for (int jb = 0; jb < H; jb += TR * kWave) {
+        float hv[TR], uv[TR][CW];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < TR; ++t) {
             const int j = jb + t * kWave + lane;
             const int jj = min(j, H - 1);
             const float x = ld_state<TH, SC1>(h, (long)i * H + jj);
@@ -319,7 +320,7 @@ __device__ __forceinline__ void class_row_energies(const void* __restrict__ h, c
         }
         if (jb == 0) under();
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < TR; ++t)
 #pragma unroll
             for (int c = 0; c < CW; ++c) e[c] = __builtin_fmaf(hv[t], uv[t][c], e[c]);
     }
@@ -433,7 +434,8 @@ __device__ __forceinline__ void class_row(const void* __restrict__ h, const floa
             if (lane == 0) e_s[QBM_MAX_CLASSES] = u;
         }
     };
-    class_row_energies<TH, CM>(h, U, cb, i, H, C, (int)threadIdx.x, e_s, under);
+    if (H > 4 * kWave) class_row_energies<TH, CM, false, decltype(under)&, 8>(h, U, cb, i, H, C, (int)threadIdx.x, e_s, under);
+    else class_row_energies<TH, CM, false, decltype(under)&, 4>(h, U, cb, i, H, C, (int)threadIdx.x, e_s, under);
     __syncthreads();
     if (w != 0) return;
     float denom = 0.f;
