@@ -58,6 +58,7 @@ json.dump({"source": "rocprofv3 --pmc SQ_* and GRBM_GUI_ACTIVE (separate passes)
            "kernels": mfma}, open(f"{out}/{R}_pmc_mfma.json", "w"), indent=1)
 print(json.dumps(mfma, indent=1)); print(json.dumps({k: v["hbm_bytes_per_launch"] for k, v in traffic.items()}))
 PY
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/kt -- python3 bench.py --steps 400 --warmup 40 --no-cpu-baseline > /dev/null 2> gpurun_out/kt.err; python tools/step_timeline.py gpurun_out/kt > $OUT/${R}_step_timeline.json; echo "timeline rc=$?" >> $P; rm -rf gpurun_out/kt
 timeout -k 10 100 python tools/stamp_kernels.py > $OUT/${R}_stamps.txt 2>&1; echo "stamps rc=$?" >> $P
 timeout -k 10 300 python bench.py > $OUT/${R}_bench.json 2> gpurun_out/bench.err; echo "bench rc=$?" >> $P
 timeout -k 10 150 python bench.py --force-dp --no-cpu-baseline > $OUT/${R}_bench_forced_dp.json 2>> gpurun_out/bench.err; echo "bench dp rc=$?" >> $P
