@@ -19,6 +19,8 @@ SHAPES = [  # (V, H, C, B)
     (784, 512, 10, 256),  # config #3/#4 per-GPU shape
     (784, 512, 2, 33),    # ragged last strip
     (100, 260, 4, 1),     # single row
+    (144, 256, 3, 70),    # 16 column strips of sample_hidden: dealt to the XCDs in pairs (H a multiple of 256), 2 grid planes
+    (96, 768, 2, 40),     # ... 48 strips, 6 grid planes
 ]
 
 
