@@ -922,14 +922,18 @@ __device__ __forceinline__ void free_energy_row(const float* __restrict__ pre, c
     }
     if (!diff && !rowloss) return;
     __syncthreads();
-    if (tid == 0 && rowloss) {
+    if (w == nw - 1 && rowloss) {
+        // the row's two loss terms by the LAST wavefront (with more wavefronts than 64-column blocks it has no `diff` column
+        // to do), lane c the exponential of class c, lanes 0 / 1 one logarithm each -- the same operations on the same values
+        // as one thread after the other (C exponentials and two logarithms in a row were the longest path of the workgroup)
+        const float ex = det_expf(p_s[min(lane, C - 1)]);
         float se = 0.f;
 #pragma unroll
         for (int c = 0; c < CM; ++c)
-            if (c < C) se = se + det_expf(p_s[c]);
+            if (c < C) se = se + __shfl(ex, c, kWave);
         const float py = p_s[lab];
-        rowloss[2 * (long)i] = det_logf(se) - py;
-        rowloss[2 * (long)i + 1] = -det_logf(py + 1e-8f);
+        const float lg = det_logf(lane == 0 ? se : py + 1e-8f);
+        if (lane < 2) rowloss[2 * (long)i + lane] = lane == 0 ? lg - py : -lg;
     }
     if (!diff) return;
     for (int j = tid; j < H; j += 64 * nw) {
