@@ -361,7 +361,8 @@ QBM_API int qbm_qbm_couplings(const double* w_label, const double* W_hh, int H, 
 
 /* Annealing range per image, beta[B,2] fp32 = (hot, cold): hot = ln 2 / max_i (|lin_i| + rowabs_i),
  * cold = ln 100 / (smallest non-zero |coefficient| of lin_b and J), cold clamped to [10 hot, 1e4 hot]; (0.1, 1) for a QUBO
- * without usable coefficients.  Replaces the automatic beta_range of the reference's annealer (dwave-neal, absent here). */
+ * without usable coefficients.  Stands where the reference's annealer (dwave-neal, absent here) derives its own default range;
+ * the rule above is THIS BUILD'S (the clamp and the QUBO-domain coefficients included): parity unpinned, DESIGN.md section 2. */
 QBM_API int qbm_qbm_beta_range(const float* lin, const double* rowabs, const double* rowmin, int B, int n, float* beta,
                                void* stream);
 
