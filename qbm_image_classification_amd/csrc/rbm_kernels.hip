@@ -285,13 +285,11 @@ __global__ __launch_bounds__(64 * H_NQ) void k_hidden(HiddenArgs a)
 // A-3  sample_class  (src/ClassificationRBM.py:54-60): exp(h.U^T + c), L1-normalised (eps 1e-12);
 // categorical draw: one uniform per row, first class whose running sum exceeds u.
 // One workgroup per row: wave w takes the classes c = w, w+4, ... (per class the sum over j is the wave tree [T],
-// exactly as one wave would do it), the energies meet in LDS (`e_s`, QBM_MAX_CLASSES floats) and thread 0 normalises
-// and draws.  All loads are unconditional.
+// exactly as one wave would do it), the energies meet in LDS (`e_s`: QBM_MAX_CLASSES floats + one slot for the row's
+// uniform) and wavefront 0 normalises and draws, lane c the quotient of class c.  All loads are unconditional.
 // ---------------------------------------------------------------------------------------------
-// class_row_energies: the 4 wavefronts of a 256-thread team (tid = 0..255) fill e_s[c] = exp(h.U_c + c_c); class_row_draw:
-// the team's thread 0 normalises and draws.  A workgroup barrier stands between the two (class_row = both, for a
-// 256-thread team that is alone in its workgroup).  `active` = false: the team has no row in this round (it only keeps
-// the workgroup's barrier count).
+// class_row_energies: the 4 wavefronts of a 256-thread team (tid = 0..255) fill e_s[c] = exp(h.U_c + c_c).  class_row = the
+// energies, a workgroup barrier, the tail on wavefront 0 -- for a 256-thread team that is alone in its workgroup.
 // under: called once by every wavefront while the loads of its first trip are in flight (class_row: the row's uniform)
 // TR: columns per lane and trip (8: a row of up to 512 hidden units is ONE round of loads, not two one after the other)
 template <class TH, int CM, bool SC1 = false, class Under = NoPre, int TR = 4>
@@ -331,38 +329,9 @@ __device__ __forceinline__ void class_row_energies(const void* __restrict__ h, c
     }
 }
 
-template <int CM>
-__device__ __forceinline__ void class_row_draw(float* __restrict__ p_out, float* __restrict__ y_out, int i, int C,
-                                               uint64_t seed, uint64_t offset, uint32_t row0, const float* __restrict__ e_s)
-{
-    float ev[CM];
-#pragma unroll
-    for (int c = 0; c < CM; ++c) ev[c] = e_s[min(c, C - 1)];
-    float denom = 0.f;
-#pragma unroll
-    for (int c = 0; c < CM; ++c)
-        if (c < C) denom = denom + __builtin_fabsf(ev[c]);
-    if (!(denom > 1e-12f)) denom = 1e-12f;
-    const float u = uniform4(seed, offset, row0 + (uint32_t)i, 0u)[0];
-    float cum = 0.f;
-    int pick = C - 1;
-    bool done = false;
-#pragma unroll
-    for (int c = 0; c < CM; ++c) {
-        if (c < C) {
-            const float p = ev[c] / denom;
-            if (p_out) p_out[(long)i * C + c] = p;
-            cum = cum + p;
-            if (!done && u < cum) { pick = c; done = true; }
-        }
-    }
-    if (y_out)
-        for (int c = 0; c < C; ++c) y_out[(long)i * C + c] = (c == pick) ? 1.f : 0.f;
-}
-
 // The same conditional by ONE wavefront (the fused chain kernel: a row per wavefront, no LDS, no workgroup barrier):
 // per class the wave tree [T] over j -- lane l chains j = l, l + 64, ... ascending, then the butterfly -- exactly what
-// one of class_row_energies' wavefronts does for its classes; lane 0 normalises and draws like class_row_draw.
+// one of class_row_energies' wavefronts does for its classes; lane 0 normalises and draws (denominator, quotients and running sum in class order).
 template <class TH, int CM, bool SC1 = false>
 __device__ __forceinline__ void class_row_wave(const void* __restrict__ h, const float* __restrict__ U,
                                                const float* __restrict__ cb, float* __restrict__ p_out,
@@ -388,33 +357,35 @@ __device__ __forceinline__ void class_row_wave(const void* __restrict__ h, const
 #pragma unroll
             for (int c = 0; c < CM; ++c) e[c] = __builtin_fmaf(hv[t], uv[t][c], e[c]);
     }
-    float ev[CM];
+    // (every lane holds every class's butterfly sum: lane c takes the exponential and the quotient of class c -- one of each
+    // instead of C in a row --, the running sum in class order is formed from the lanes' quotients: the same operations on the
+    // same values as one thread after the other)
+    float mine = 0.f;
 #pragma unroll
-    for (int c = 0; c < CM; ++c) ev[c] = det_expf(wave_butterfly_sum(e[c]) + cb[min(c, C - 1)]);
-    if (lane != 0) return;
+    for (int c = 0; c < CM; ++c) {
+        const float t = wave_butterfly_sum(e[c]) + cb[min(c, C - 1)];
+        mine = (lane == c || (c == C - 1 && lane >= C)) ? t : mine;
+    }
+    mine = det_expf(mine);
     float denom = 0.f;
 #pragma unroll
     for (int c = 0; c < CM; ++c)
-        if (c < C) denom = denom + __builtin_fabsf(ev[c]);
+        if (c < C) denom = denom + __builtin_fabsf(__shfl(mine, c, kWave));
     if (!(denom > 1e-12f)) denom = 1e-12f;
     const float u = uniform4(seed, offset, row0 + (uint32_t)i, 0u)[0];
+    const float p = mine / denom;
+    if (p_out && lane < C) p_out[(long)i * C + lane] = p;
     float cum = 0.f;
     int pick = C - 1;
     bool done = false;
 #pragma unroll
     for (int c = 0; c < CM; ++c) {
         if (c < C) {
-            const float p = ev[c] / denom;
-            if (p_out) p_out[(long)i * C + c] = p;
-            cum = cum + p;
+            cum = cum + __shfl(p, c, kWave);
             if (!done && u < cum) { pick = c; done = true; }
         }
     }
-    if (y_out) {
-#pragma unroll
-        for (int c = 0; c < CM; ++c)
-            if (c < C) y_out[(long)i * C + c] = (c == pick) ? 1.f : 0.f;
-    }
+    if (y_out && lane < C) y_out[(long)i * C + lane] = (lane == pick) ? 1.f : 0.f;
 }
 
 template <class TH, int CM>
@@ -425,8 +396,8 @@ __device__ __forceinline__ void class_row(const void* __restrict__ h, const floa
 {
     // The row's uniform is drawn by the last wavefront UNDER its first loads and parked behind the energies; the tail is then
     // one wavefront's: lane c divides class c (one division in parallel instead of C in a row on one lane), every lane forms
-    // the running sum in class order from the lanes' quotients -- the same operations on the same values as class_row_draw
-    // (which the 8-rows-per-workgroup form keeps), a third of its instructions on the path to y.
+    // the running sum in class order from the lanes' quotients -- the same operations on the same values as one thread doing
+    // them in a row (class_row_wave's tail), a third of the instructions on the path to y.
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
     auto under = [&]() {
         if (w == 3) {
