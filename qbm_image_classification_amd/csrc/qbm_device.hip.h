@@ -113,10 +113,33 @@ __device__ __forceinline__ float det_softplus(float z) { return det_logf(1.0f + 
 // Wave tree [T]: butterfly p[l] = p[l] + p[l ^ off], off = 32..1.  fp32 addition is commutative,
 // so every lane ends with the same bits.
 // ---------------------------------------------------------------------------------------------
+// On the vector ALU only -- no ds_bpermute round trips (a __shfl_xor each: ~130 cycles of LDS-crossbar latency per step, six
+// dependent steps per sum, ten sums per row of the class conditional):
+//   off 32 / 16  v_permlane32_swap / v_permlane16_swap of the value with a copy of itself leave {lower, lower} and {upper,
+//                upper} halves (even / odd rows) in the two registers: their sum IS p[l] + p[l ^ off] in every lane;
+//   off 8        row_ror:8;   off 4   row_shl:4 into banks 0, 2 and row_shr:4 into banks 1, 3;   off 2, 1   quad_perm.
+// The same pairs in the same order as the shuffles: the same bits.
 __device__ __forceinline__ float wave_butterfly_sum(float p)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) p = p + __shfl_xor(p, off, kWave);
+    {
+        const unsigned x = __float_as_uint(p);
+        const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        p = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    {
+        const unsigned x = __float_as_uint(p);
+        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        p = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    p = p + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(p), 0x128, 0xF, 0xF, false));   // row_ror:8
+    {
+        const unsigned x = __float_as_uint(p);
+        unsigned t = __builtin_amdgcn_update_dpp(0u, x, 0x104, 0xF, 0x5, false);   // row_shl:4: lanes with bit 2 clear read l + 4
+        t = __builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false);            // row_shr:4: lanes with bit 2 set read l - 4
+        p = p + __uint_as_float(t);
+    }
+    p = p + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(p), 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+    p = p + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(p), 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
     return p;
 }
 
