@@ -67,15 +67,20 @@ struct JTri {
     {
         // wave-uniform: T(p, i) at tri + up + 4 i for i >= p; one vector add per tile in front of its read.
         // up = 4 (p n - p (p - 1) / 2 - p) = 2 p (2 n - 1 - p) is what lane p % 64 holds as ci[T]: ONE v_readlane instead of
-        // four scalar instructions -- the flip loop is bound by the SIMD's scalar issue slot (one per 4 cycles, shared by its
-        // 3.75 wavefronts), not by latency: two chains in lockstep in one wavefront were 18 % SLOWER
+        // four scalar instructions -- the flip loop is bound by the NUMBER of instructions it issues (a SIMD hands its 3.75
+        // wavefronts one scalar and one vector slot every 4 cycles), not by latency: two chains in lockstep in one wavefront,
+        // same count per flip plus null steps, were 18 % SLOWER
         const int up = __builtin_amdgcn_readlane(ci[T], p & 63), p4 = 4 * p;
         const char* base = reinterpret_cast<const char*>(tri);
+        // the later tiles lie 256 bytes apart behind ONE address (up + 4 lane): immediate offsets, and the compiler pairs the
+        // reads (ds_read2st64_b32).  Phantom lanes of the last tile read up to 252 bytes beyond the row -- the next rows, or the
+        // 256 zeroed bytes the kernel keeps behind the triangle: finite values for fields nobody tests.
+        const int rb = up + 4 * lane;
 #pragma unroll
         for (int tt = 0; tt < NF; ++tt) {
             int ad;
             if (tt < T) ad = ci[tt] + p4;                // every spin of an earlier tile is below p
-            else if (tt > T) ad = up + ic[tt];           // every spin of a later tile is above p
+            else if (tt > T) ad = rb + 256 * tt;         // every spin of a later tile is above p
             else ad = (ic[tt] >= p4) ? up + ic[tt] : ci[tt] + p4;
             out[tt] = *reinterpret_cast<const float*>(base + ad);
         }
@@ -234,6 +239,7 @@ __global__ __launch_bounds__(64 * kGibbsLdsWaves) void k_qubo_gibbs_lds(const fl
         const int S = r * n - (r * (r - 1)) / 2;
         for (int c = r + lane; c < n; c += 64) tri[S + c - r] = J[(long)r * n + c];
     }
+    if (threadIdx.x < 64) tri[n * (n + 1) / 2 + threadIdx.x] = 0.f;   // (the pad JTri::row's phantom lanes may read)
     __syncthreads();
     JTri<NF> jr{tri, n, {}, {}};
     jr.setup(lane);
@@ -479,9 +485,9 @@ int launch_gibbs(const float* lin, const float* J, int B, int R, int n, int swee
     const size_t tri_bytes = (size_t)n * (n + 1) / 2 * sizeof(float);
     if constexpr (NF <= 5) if (tri_bytes <= 150 * 1024 && nch >= 64) {
         // the triangle of J fits the LDS of a CU (n <= 276): one persistent workgroup per CU, rows of J read from LDS
-        if (tri_bytes > 65536) {
+        if (tri_bytes + 256 > 65536) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_qubo_gibbs_lds<NF>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)tri_bytes);
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)tri_bytes + 256);
             if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_qubo_gibbs_lds)");
         }
         // one workgroup per CU (256), as many wavefronts as even out the rounds: every wave walks `rounds` chains
@@ -489,7 +495,7 @@ int launch_gibbs(const float* lin, const float* J, int B, int R, int n, int swee
         const int rounds = (nch + wgs * kGibbsLdsWaves - 1) / (wgs * kGibbsLdsWaves);
         int waves = (nch + rounds * wgs - 1) / (rounds * wgs);
         waves = waves < 1 ? 1 : waves > kGibbsLdsWaves ? kGibbsLdsWaves : waves;
-        hipLaunchKernelGGL((k_qubo_gibbs_lds<NF>), dim3(wgs), dim3(64 * waves), tri_bytes, st, lin, J, nch, R, n, sweeps,
+        hipLaunchKernelGGL((k_qubo_gibbs_lds<NF>), dim3(wgs), dim3(64 * waves), tri_bytes + 256, st, lin, J, nch, R, n, sweeps,
                            beta0, beta1, beta_dev, seed, offset, chain0, states);
         QBM_CHECK_LAUNCH("k_qubo_gibbs_lds");
         return QBM_OK;
