@@ -337,12 +337,24 @@ __global__ __launch_bounds__(64) void k_linear_fields(const double* __restrict__
     // their latencies overlap instead of adding up
     const double* w = W_vh + (long)H + j;
     int k = 0;
-    for (; k + 8 <= D; k += 8) {
-        double xv[8], wv[8];
+    // ... and the next 8 are requested before the current 8 are added up (the chain of 2 D dependent float64 operations is
+    // what the kernel should wait for, not a round trip to L2 per group of 8)
+    constexpr int G = 8;
+    if (D >= 2 * G) {
+        double xv[G], wv[G], xn[G], wn[G];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { xv[u] = x[k + u]; wv[u] = w[(long)(k + u) * H]; }
+        for (int u = 0; u < G; ++u) { xv[u] = x[u]; wv[u] = w[(long)u * H]; }
+        for (; k + 2 * G <= D; k += G) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a += xv[u] * wv[u];
+            for (int u = 0; u < G; ++u) { xn[u] = x[k + G + u]; wn[u] = w[(long)(k + G + u) * H]; }
+#pragma unroll
+            for (int u = 0; u < G; ++u) a += xv[u] * wv[u];
+#pragma unroll
+            for (int u = 0; u < G; ++u) { xv[u] = xn[u]; wv[u] = wn[u]; }
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u) a += xv[u] * wv[u];
+        k += G;
     }
     for (; k < D; ++k) a += x[k] * w[(long)k * H];
     lin[idx] = (float)((b_h[j] + a) / beta_eff);
