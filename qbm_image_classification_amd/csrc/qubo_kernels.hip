@@ -260,8 +260,17 @@ __global__ __launch_bounds__(256) void k_read_mean(const uint8_t* __restrict__ s
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * n) return;
     const int b = idx / n, i = idx % n;
-    int cnt = 0;
-    for (int r = 0; r < R; ++r) cnt += states[((long)b * R + r) * n + i];
+    int cnt = 0;   // (an integer count: any order; 10 reads requested together instead of one round trip per read)
+    const uint8_t* s = states + (long)b * R * n + i;
+    int r = 0;
+    for (; r + 10 <= R; r += 10) {
+        int v[10];
+#pragma unroll
+        for (int u = 0; u < 10; ++u) v[u] = s[(long)(r + u) * n];
+#pragma unroll
+        for (int u = 0; u < 10; ++u) cnt += v[u];
+    }
+    for (; r < R; ++r) cnt += s[(long)r * n];
     mean[idx] = (double)cnt / (double)R;
 }
 
