@@ -6,7 +6,9 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "libqbm_hip.so")
+# QBM_HIP_LIB: another build of the SAME library (a diagnostic / experiment build of csrc/, e.g. tools/stamp_kernels.py's): a
+# developer's switch for A/B timing inside one GPU session, never a fallback -- the file must exist and pass the ABI check
+SO = os.environ.get("QBM_HIP_LIB") or os.path.join(HERE, "libqbm_hip.so")
 
 QBM_ABI_VERSION = 13
 QBM_MAX_CLASSES = 15

@@ -485,6 +485,16 @@ struct VisibleArgs {
 
 // 8 wavefronts (512 threads) per strip workgroup: wavefront q contracts chain q of the 8 the K = H terms are cut into
 // ([Q] with NQ = 8); two visible units per thread in the epilogue.
+// Request stagger of the visible strips (strip_mma's STAG, units of 64 cycles): with 16 the second wavefront of every SIMD asks
+// for its operands ~1000 cycles behind the first, whose MFMAs then start earlier: k_visible 6.55 -> 6.36 us (8: 6.41, 32: 6.48,
+// 48: 6.85; A/B in one session through QBM_HIP_LIB).  The same stagger LOSES in k_hidden (5.90 -> 5.97 / 6.11 us at 8 / 16).
+#ifndef QBM_VIS_STAGGER
+#define QBM_VIS_STAGGER 16
+#endif
+// (the visible phases of the fused chain: PCD-10 128.8 - 129.2 -> 128.3 us per step with 16, 128.5 with 8)
+#ifndef QBM_CHAIN_VIS_STAGGER
+#define QBM_CHAIN_VIS_STAGGER 16
+#endif
 constexpr int V_NQ = 8;
 // The body of strip (ms, ns) of (16 MT) x (16 NT) outputs; the caller is a 512-thread workgroup.  AUX: cache policy of the
 // loads of h (kSc1 inside the fused chain kernel).
@@ -532,7 +542,7 @@ __device__ __forceinline__ void visible_body(const VisibleArgs& a, int ms, int n
         asm volatile("" : "+v"(uu[0]), "+v"(uu[1]));   // not sunk into the epilogue
     };
     QBM_STAMP(11);
-    const auto o = strip_mma<MT, NT, FAST, FAST, 2, NQ, true, AUX>(A, Bv, m0, n0, a.H, lds, a.KP, pre0, pre);
+    const auto o = strip_mma<MT, NT, FAST, FAST, 2, NQ, true, AUX, 0, kWhole, (AUX == 0 ? QBM_VIS_STAGGER : QBM_CHAIN_VIS_STAGGER)>(A, Bv, m0, n0, a.H, lds, a.KP, pre0, pre);
     if (o.valid(0) && i < a.B && k0 < a.V && st_w == 0u) {
         const float sv[2] = {o.sum[0].x, o.sum[0].y};
         float pv[2], vv[2];

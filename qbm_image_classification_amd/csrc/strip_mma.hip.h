@@ -427,7 +427,7 @@ __device__ __forceinline__ int chain_transfers_b(int K, int KP)
     return NT * ((klen + 15) >> 4);
 }
 template <int MT, int NT, bool FAST_A, bool FAST_B, int CPT = 4, int NQ = 4, bool KPERM = false, int AUX_A = 0, int AUX_B = 0,
-          int PHASE = kWhole, class AView, class BView, class Pre0 = NoPre, class Pre = NoPre, class Post = NoPre>
+          int PHASE = kWhole, int STAG = 0, class AView, class BView, class Pre0 = NoPre, class Pre = NoPre, class Post = NoPre>
 __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView& A, const BView& Bv, int m0, int n0, int K,
                                                                     char* __restrict__ lds, int KP, Pre0&& pre0 = NoPre{},
                                                                     Pre&& pre = NoPre{}, int stamp0 = 0,
@@ -708,6 +708,10 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
             }
         } else {
         const int ahead = QBM_DMA_AHEAD > 0 ? QBM_DMA_AHEAD : (quads <= 2 ? 1 : 2);
+        // STAG > 0 (NQ = 8): the second wavefront of every SIMD requests its operands 64 STAG cycles later -- the first one's
+        // land ahead of them and its MFMAs start while the other's are still on their way
+        if constexpr (STAG > 0 && NQ == 8)
+            if (q >= 4) __builtin_amdgcn_s_sleep(STAG);
         if (qbm_diag != 4 && quads > 0) issue_quad(0);
         pre0();
         if (ahead >= 2 && qbm_diag != 4 && quads > 1) issue_quad(1);
