@@ -481,6 +481,7 @@ struct VisibleArgs {
     uint32_t* hg_round;       // non-null: the fused tail of the step (k_hgrad) is the next launch: this one advances the word
                               // that launch takes its barrier round from (one writer, a kernel boundary in front of the readers:
                               // the same number in every workgroup whatever shapes earlier launches on the buffer had)
+    int stag;                 // the strips stagger their requests (QBM_VIS_STAGGER): where a CU holds ONE strip workgroup and the chains are long
 };
 
 // 8 wavefronts (512 threads) per strip workgroup: wavefront q contracts chain q of the 8 the K = H terms are cut into
@@ -488,6 +489,7 @@ struct VisibleArgs {
 // Request stagger of the visible strips (strip_mma's STAG, units of 64 cycles): with 16 the second wavefront of every SIMD asks
 // for its operands ~1000 cycles behind the first, whose MFMAs then start earlier: k_visible 6.55 -> 6.36 us (8: 6.41, 32: 6.48,
 // 48: 6.85; A/B in one session through QBM_HIP_LIB).  The same stagger LOSES in k_hidden (5.90 -> 5.97 / 6.11 us at 8 / 16).
+// Switched on per launch (VisibleArgs::stag).
 #ifndef QBM_VIS_STAGGER
 #define QBM_VIS_STAGGER 16
 #endif
@@ -542,7 +544,8 @@ __device__ __forceinline__ void visible_body(const VisibleArgs& a, int ms, int n
         asm volatile("" : "+v"(uu[0]), "+v"(uu[1]));   // not sunk into the epilogue
     };
     QBM_STAMP(11);
-    const auto o = strip_mma<MT, NT, FAST, FAST, 2, NQ, true, AUX, 0, kWhole, (AUX == 0 ? QBM_VIS_STAGGER : QBM_CHAIN_VIS_STAGGER)>(A, Bv, m0, n0, a.H, lds, a.KP, pre0, pre);
+    const auto o = strip_mma<MT, NT, FAST, FAST, 2, NQ, true, AUX, 0, kWhole, (AUX == 0 ? QBM_VIS_STAGGER : QBM_CHAIN_VIS_STAGGER)>(A, Bv, m0, n0, a.H, lds, a.KP, pre0, pre, 0, nullptr, false, NoPre{}, 0,
+                                                                                                          AUX != 0 || a.stag != 0);
     if (o.valid(0) && i < a.B && k0 < a.V && st_w == 0u) {
         const float sv[2] = {o.sum[0].x, o.sum[0].y};
         float pv[2], vv[2];
@@ -1920,6 +1923,10 @@ int launch_visible_t(const qbm_rbm_params* P, const void* h, int B, float* p_v, 
                       aligned8(P->b),
                   P->U, P->c, p_y, y1hot, P->C, offset_y, with_class ? (B <= 512 ? B : (B + NQ - 1) / NQ) : 0, status, 0, nullptr, nullptr, nullptr, nullptr, 0, div_magic(nM),
                   draw_base, status ? hg_round : nullptr};
+    // the request stagger pays where a CU holds one strip workgroup and a wavefront's chain is a whole quad (784 x 512, B = 256:
+    // 6.55 -> 6.36 us); with several workgroups per CU they fill each other's gaps, and it costs (B = 2048: 121.8 -> 122.4 us
+    // per step; 784 x 128, B = 128: +0.3 us)
+    a.stag = (nM * nN <= 256 && P->H >= 256) ? 1 : 0;
     if (mon && a.n_aux == B) {   // (visible_takes_monitor: the caller has asked)
         a.n_fe = B; a.fe_pre = mon->mon_pre; a.fe_labels = mon->mon_labels; a.fe_p = mon->mon_p; a.fe_rowloss = mon->mon_rowloss;
     }

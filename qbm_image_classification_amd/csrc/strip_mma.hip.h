@@ -432,7 +432,8 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
                                                                     char* __restrict__ lds, int KP, Pre0&& pre0 = NoPre{},
                                                                     Pre&& pre = NoPre{}, int stamp0 = 0,
                                                                     char* __restrict__ ldsB = nullptr, bool b_resident = false,
-                                                                    Post&& post = NoPre{}, int younger = 0)
+                                                                    Post&& post = NoPre{}, int younger = 0,
+                                                                    bool stag_on = true)
 {
     static_assert(PHASE == kWhole || (FAST_A && FAST_B), "the two-call form takes LDS-DMA operands");
     // ldsB != nullptr: the B images live in a region of their own (NQ * strip_wave_bytes_b<NT>(KP) bytes) instead of behind
@@ -710,8 +711,9 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
         const int ahead = QBM_DMA_AHEAD > 0 ? QBM_DMA_AHEAD : (quads <= 2 ? 1 : 2);
         // STAG > 0 (NQ = 8): the second wavefront of every SIMD requests its operands 64 STAG cycles later -- the first one's
         // land ahead of them and its MFMAs start while the other's are still on their way
+        // (stag_on: the caller's run-time say)
         if constexpr (STAG > 0 && NQ == 8)
-            if (q >= 4) __builtin_amdgcn_s_sleep(STAG);
+            if (q >= 4 && stag_on) __builtin_amdgcn_s_sleep(STAG);
         if (qbm_diag != 4 && quads > 0) issue_quad(0);
         pre0();
         if (ahead >= 2 && qbm_diag != 4 && quads > 1) issue_quad(1);
