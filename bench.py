@@ -109,22 +109,33 @@ def main():
     ws = ops.cd_workspace(P, B)
     cws = CdWorkspace(*(ptr(t) for t in ws))
     ps, gs = P.struct(), G.struct()
+    gs_dp = G.struct(with_count=True)     # data parallel: the gradient launch stores its row count behind the gradient blocks
     global_B = float(B * world)
+    # every per-step argument is built ONCE (device pointers of the resident minibatches, the two structs): a step on the
+    # host is then one ctypes call -- and, data parallel, one collective
+    vp = [ptr(t) for t in data_v]
+    yp = [ptr(t) for t in data_y]
+    pps, pgs, pgd, pcw = C.byref(ps), C.byref(gs), C.byref(gs_dp), C.byref(cws)
+    cd_step, dp_step, upd_dev = lib.qbm_rbm_cd_step, lib.qbm_rbm_dp_step, lib.qbm_rbm_update_dev
+    SUM = dist.ReduceOp.SUM
 
-    def step(i, stream):
-        """one CD-1 update on resident minibatch i % NB"""
+    def step(i, stream, first=False):
+        """one CD-1 update on resident minibatch i % NB.  Data parallel: ONE C-ABI call (the update of the step before from the
+        all-reduced buffer, its global row count read on the device, then this minibatch's chain and gradient:
+        qbm_rbm_dp_step) and ONE collective (the flat gradient buffer with the row count, RCCL over xGMI); `first`: no update
+        is pending.  The last update of a run is applied by flush()."""
         j = i % NB
-        off = 4 * i
         if not dp:
-            check(lib.qbm_rbm_cd_step(C.byref(ps), C.byref(gs), ptr(data_v[j]), QBM_U8, ptr(data_y[j]), B, K_CD, 42, off,
-                                      row_base, None, None, C.byref(cws), 1, lr, factor, global_B, sparse, stream),
-                  "qbm_rbm_cd_step")
+            check(cd_step(pps, pgs, vp[j], QBM_U8, yp[j], B, K_CD, 42, 4 * i, row_base, None, None, pcw, 1, lr, factor, global_B,
+                          sparse, stream), "qbm_rbm_cd_step")
         else:
-            check(lib.qbm_rbm_cd_step(C.byref(ps), C.byref(gs), ptr(data_v[j]), QBM_U8, ptr(data_y[j]), B, K_CD, 42, off,
-                                      row_base, None, None, C.byref(cws), 0, lr, factor, global_B, sparse, stream),
-                  "qbm_rbm_cd_step")
-            dist.all_reduce(G.flat, op=dist.ReduceOp.SUM)          # RCCL over xGMI, one collective per step
-            check(lib.qbm_rbm_update(C.byref(ps), C.byref(gs), lr, factor, global_B, sparse, stream), "qbm_rbm_update")
+            check(dp_step(pps, pgd, vp[j], QBM_U8, yp[j], B, K_CD, 42, 4 * i, row_base, None, None, pcw, 0 if first else 1, lr,
+                          factor, sparse, stream), "qbm_rbm_dp_step")
+            dist.all_reduce(G.flat, op=SUM)
+
+    def flush(stream):
+        if dp:
+            check(upd_dev(pps, pgd, lr, factor, 0.0, ptr(G.count), sparse, None, stream), "qbm_rbm_update_dev")
 
     def cur():
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -143,12 +154,14 @@ def main():
         S = args.graph
         try:
             for i in range(S):
-                step(i, cur())
+                step(i, cur(), first=(i == 0))
+            flush(cur())
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 for i in range(S):
-                    step(i, cur())
+                    step(i, cur(), first=(i == 0))
+                flush(cur())                      # S chains, S collectives, S updates per replay
             graphs = (g, S)
         except Exception as e:   # noqa: BLE001
             graph_note = f"graph capture of the data-parallel step failed ({type(e).__name__}: {str(e)[:120]}): eager launches"
@@ -166,15 +179,22 @@ def main():
         graphs = (g, S)
 
     def run(nsteps):
+        """exactly nsteps CD-1 updates (data parallel: nsteps chains, nsteps collectives, nsteps updates)"""
         if graphs is None:
+            st = cur()
             for i in range(nsteps):
-                step(i, cur())
+                step(i, st, first=(i == 0))
+            if nsteps:
+                flush(st)
         else:
             g, S = graphs
             for _ in range(nsteps // S):
                 g.replay()
+            st = cur()
             for i in range(nsteps % S):
-                step(i, cur())
+                step(i, st, first=(i == 0))
+            if nsteps % S:
+                flush(st)
 
     def barrier():
         if dp:
@@ -266,10 +286,14 @@ def main():
     run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    per_rank_ms = None
     if dp:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        # every rank's own clock around the same region (a future SCALE record shows which rank lags), then the MAX over ranks
+        t = torch.zeros(world, device=dev, dtype=torch.float64)
+        t[rank] = dt
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per_rank_ms = [round(x / args.steps * 1e3, 5) for x in t.tolist()]
+        dt = float(t.max().item())
     assert torch.isfinite(P.W).all(), "parameters diverged"
     assert int(ws[5][512].item()) == 0, "a launch that synchronises workgroups inside an XCD gave up during the timed run"
 
@@ -314,13 +338,14 @@ def main():
     if rank == 0:
         out = {
             "metric": "gibbs_samples_per_sec", "value": round(value, 1), "unit": "samples/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "per_rank_ms_per_step": per_rank_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "ClassificationRBM 784v x 512h, C=10, CD-1, batch 256 per GPU (BASELINE.json configs[3] shape; "
                                    "global batch 256*N, RCCL all-reduce of the flat gradient per step when N>1)",
                        "batch_per_gpu": B, "cd_k": K_CD, "warmup_steps_run": warm_steps,
                        "pre_timed_kernel_launches": (1000 + 55 + 5) * len(timed),
                        "launches_per_step": "k_hidden, k_visible, k_hgrad" if any("k_hgrad" in k for k in timed) else "k_hidden, k_visible, k_hidden, k_grad (+ all-reduce, k_update when data-parallel)",
+                       "host_calls_per_step": "1 C-ABI call (qbm_rbm_dp_step) + 1 collective" if dp else "1 C-ABI call (qbm_rbm_cd_step)",
                        "draws": "a replayed graph repeats the draw ids and minibatches it captured (same work per step)" if graphs else "fresh draw ids per step", "launch": (f"hipGraph x{graphs[1]} steps" if graphs else "eager") + (f" ({graph_note})" if graph_note else ""),
                        "parallelism": f"dp{world}" + (" (forced data-parallel path)" if args.force_dp and world == 1 else "")},
             "visible_unit_updates_per_sec": round(value * V, 1),

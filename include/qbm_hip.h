@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QBM_ABI_VERSION 13
+#define QBM_ABI_VERSION 14
 #define QBM_MAX_CLASSES 15 /* class rows + the bias row share one 16-row gradient tile */
 #define QBM_MAX_QUBO_VARS 1024
 
@@ -170,7 +170,10 @@ typedef struct {
                      * different XCDs); 3 / 4 = the fused tail gave up (barrier / placement).  Words 513 / 514: `offset`
                      * (low / high half) of the step that gave up; word 515: the round of a fused tail that gave up (516: round counter).
                      * FAIL-SAFE: while the status word is set, EVERY later launch of qbm_rbm_cd_step on this buffer stores
-                     * nothing (n_rows becomes -inf), and so does qbm_rbm_update_dev when handed the word.  Status 1 / 2:
+                     * nothing (n_rows becomes -inf) -- also the steps whose SHAPE the fused launches do not take (the short
+                     * last minibatch of an epoch): wherever the mode would hand a step with uint8 data to a fused launch,
+                     * an ineligible shape runs one launch per phase with every storing launch reading the word -- and so
+                     * do qbm_rbm_update_dev and qbm_rbm_disc_step_ex (qbm_rbm_disc_workspace.status) when handed the word.  Status 1 / 2:
                      * the step's gradient launch did nothing either -- parameters and workspace are as before the step,
                      * which the caller repeats with qbm_rbm_fused_chain_mode(0) after re-zeroing the buffer.  Status 3 / 4
                      * with fuse_update: the column groups that got through their barrier HAVE been updated, the others
@@ -230,6 +233,15 @@ QBM_API int qbm_rbm_cd_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, con
                             uint8_t* chain_v, float* chain_y, const qbm_rbm_cd_workspace* ws, int fuse_update,
                             float lr, float factor, float batch_size, float sparse_constant, void* stream);
 
+/* One data-parallel CD-k / PCD step as ONE call: [apply_pending != 0: the update of the step BEFORE, from the
+ * all-reduced G with its row count G->n_rows read on the device -- qbm_rbm_update_dev --] then chain + gradient of this
+ * minibatch into G (all five blocks and n_rows required; B == 0 zeroes them).  The caller all-reduces the flat buffer between
+ * two calls and applies the last step's update with qbm_rbm_update_dev: per step one call and one collective on the host. */
+QBM_API int qbm_rbm_dp_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void* v0, int v0_dtype, const float* y0,
+                            int B, int k, uint64_t seed, uint64_t offset, uint32_t row0, uint8_t* chain_v, float* chain_y,
+                            const qbm_rbm_cd_workspace* ws, int apply_pending, float lr, float factor, float sparse_constant,
+                            void* stream);
+
 /* Completes a step whose fused tail gave up (qbm_rbm_cd_workspace.sync: status 3 / 4): the arguments of that
  * qbm_rbm_cd_step call and word 515 of the sync buffer as `round`; to be called before the buffer is re-zeroed and before
  * anything else touches the workspace.  Two launches: the hidden phases, then the gradient items, that the workgroups of
@@ -258,6 +270,9 @@ typedef struct {
     double* loss_acc; /* optional, [2]: += the minibatch means (fp32: quartered chain over the rows, / B) of the two columns of
                        * rowloss, i.e. the reference's `epoch_error += batch_error.item()` and `epoch_nll += nll.item()`
                        * (:187, :191) on the device -- the training loop reads them once per epoch */
+    const uint32_t* status; /* optional: the status word of a CD workspace (qbm_rbm_cd_workspace.sync + 512) -- hybrid training
+                             * interleaves discriminative and CD steps: while the word is set the step stores nothing (p_y,
+                             * gradients, parameters, loss_acc; n_rows becomes -inf), like the CD steps around it */
 } qbm_rbm_disc_workspace;
 
 /* ClassificationRBM.discriminative_training, src/ClassificationRBM.py:101-146: p_y[B,C] = p(y|x) before the update (returned

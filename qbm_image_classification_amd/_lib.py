@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # developer's switch for A/B timing inside one GPU session, never a fallback -- the file must exist and pass the ABI check
 SO = os.environ.get("QBM_HIP_LIB") or os.path.join(HERE, "libqbm_hip.so")
 
-QBM_ABI_VERSION = 13
+QBM_ABI_VERSION = 14
 QBM_MAX_CLASSES = 15
 QBM_F32, QBM_U8 = 0, 1
 
@@ -42,7 +42,8 @@ QBM_CD_SYNC_WORDS = 3136
 
 
 class DiscWorkspace(C.Structure):
-    _fields_ = [("pre", C.c_void_p), ("diff", C.c_void_p), ("rowloss", C.c_void_p), ("loss_acc", C.c_void_p)]
+    _fields_ = [("pre", C.c_void_p), ("diff", C.c_void_p), ("rowloss", C.c_void_p), ("loss_acc", C.c_void_p),
+                ("status", C.c_void_p)]   # optional: status word of a CD workspace (hybrid training's fail-safe)
 
 
 _p = C.c_void_p
@@ -72,6 +73,7 @@ SIGNATURES = {
     "qbm_rbm_cd_chain": [_PP, _p, _i, _p, _i, _i, _u64, _u64, _u32, _p, _p, C.POINTER(CdWorkspace), _p],
     "qbm_rbm_cd_step": [_PP, _GP, _p, _i, _p, _i, _i, _u64, _u64, _u32, _p, _p, C.POINTER(CdWorkspace), _i, _f, _f,
                         _f, _f, _p],
+    "qbm_rbm_dp_step": [_PP, _GP, _p, _i, _p, _i, _i, _u64, _u64, _u32, _p, _p, C.POINTER(CdWorkspace), _i, _f, _f, _f, _p],
     "qbm_rbm_cd_step_finish": [_PP, _GP, _p, _i, _p, _i, _i, _u64, _u64, _u32, _p, _p, C.POINTER(CdWorkspace), _i, _f, _f,
                                _f, _f, _u32, _p],
     "qbm_rbm_cd_tail": [_PP, _GP, _p, _i, _p, _i, _p, _p, C.POINTER(CdWorkspace), _i, _f, _f, _f, _f, _u32, _p],

@@ -180,22 +180,28 @@ class ClassificationRBM:
 
         return dist.get_rank() * int(self._rank_rows if self._rank_rows else local_rows)
 
-    def _disc_step(self, input_data, class_label, factor, loss_acc=None, p_out=None):
+    def _disc_step(self, input_data, class_label, factor, loss_acc=None, p_out=None, guard_chain=False):
         """One discriminative pass + update (single GPU: everything in three launches; data parallel: + the all-reduce and
-        the update launch) -> p(y|x).  loss_acc: float64 [2] device tensor the step adds its two loss terms to."""
+        the update launch) -> p(y|x).  loss_acc: float64 [2] device tensor the step adds its two loss terms to.
+        guard_chain (hybrid training): the step reads the fused chain launches' status word and is recorded with the pending CD
+        steps -- behind a CD step that gave up it stores nothing and HipRbmOps.check_chain_status repeats it in order."""
         batch_size = input_data.size(0)
         P = self._params()
         self.visible_bias_grad = 0  # :138
         lr, sp = float(self.learning_rate), float(self.sparse_constant)
+        G, f, bs = self._grads, float(factor), float(batch_size)
         if self.data_parallel:
-            p = self.ops.disc_step(P, self._grads, input_data, class_label, False, False, lr, float(factor),
-                                   float(batch_size), sp, with_count=True, loss_acc=loss_acc, p_out=p_out)
-            self._allreduce_grads()
-            self.ops.update(P, self._grads, lr, float(factor), 0.0, sp, with_gb=False, count_dev=self._grads.count)
+            def step(guard=guard_chain):
+                p = self.ops.disc_step(P, G, input_data, class_label, False, False, lr, f, bs, sp, with_count=True, loss_acc=loss_acc,
+                                       p_out=p_out, **(dict(guard_chain=True, replay=lambda: step(False)) if guard else {}))
+                self._allreduce_grads()
+                self.ops.update(P, G, lr, f, 0.0, sp, with_gb=False, count_dev=G.count)
+                return p
         else:
-            p = self.ops.disc_step(P, self._grads, input_data, class_label, True, not self.keep_grads, lr,
-                                   float(factor), float(batch_size), sp, loss_acc=loss_acc, p_out=p_out)
-        return p
+            def step(guard=guard_chain):
+                return self.ops.disc_step(P, G, input_data, class_label, True, not self.keep_grads, lr, f, bs, sp, loss_acc=loss_acc,
+                                          p_out=p_out, **(dict(guard_chain=True, replay=lambda: step(False)) if guard else {}))
+        return step()
 
     def discriminative_training(self, input_data, class_label, factor=1):
         """src/ClassificationRBM.py:101-146 -> (error, predicted, class_probabilities)"""
@@ -258,7 +264,7 @@ class ClassificationRBM:
         if self.data_parallel:
             def step():
                 self.ops.cd_step(P, G, v0, y0, k, seed, offset, row0, cv, cy, False, lr, f, bs, sp, with_count=True, replay=step,
-                                 monitor=monitor)
+                                 monitor=monitor, draw_base=draw_base)
                 self._allreduce_grads()
                 self.ops.update(P, G, lr, f, 0.0, sp, count_dev=G.count)   # global batch size read on the device
         elif self.keep_grads:
@@ -307,16 +313,25 @@ class ClassificationRBM:
         # the loss sums are device memory), so from the second epoch on an epoch costs the host one gather and one replay --
         # the loop then runs at the kernels' speed whatever the host's (eager launches sit at the edge of being host-bound:
         # ~25 us of Python + launch calls per 25 us step).  Same launches, same order: same bits.
-        graph_ok = (resident and method in ('discriminative', 'generative') and not self.data_parallel and self.device.type == 'cuda'
+        # Data parallel (one process per GPU): the step's RCCL all-reduce of the flat gradient buffer and the update launch that
+        # reads the all-reduced row count on the device are captured with it -- every rank captures the same number of steps (a
+        # rank whose shard of a short last minibatch is empty still zeroes its gradient blocks and takes part), so the
+        # data-parallel loop is not host-bound either (eager: five launches and a collective per step from Python).
+        graph_ok = (resident and method in ('discriminative', 'generative') and self.device.type == 'cuda'
                     and getattr(train_loader, 'epoch_gather', False) and hasattr(self.ops, 'lib')
                     and os.environ.get('QBM_EPOCH_GRAPH', '1') != '0')
         # The generative rules draw random numbers: their captured launches carry draw ids and Philox rows RELATIVE to the epoch,
         # and two device words (qbm_rbm_cd_workspace.draw_base) carry the epoch's base -- moved between replays, so the draws
         # are those of the eager loop.  Only where the step is one launch per phase (CD-1 by default: the one-launch chain keeps
-        # its fail-safe record on the host, per step) and the update rides in the gradient launch.
+        # its fail-safe record on the host, per step) and the update rides in the gradient launch (or, data parallel, behind the
+        # collective).
         if graph_ok and method == 'generative':
             from ._lib import QBM_U8
-            graph_ok = not self.keep_grads and not self.ops._may_fuse(self.k, QBM_U8)
+            graph_ok = (self.data_parallel or not self.keep_grads) and not self.ops._may_fuse(self.k, QBM_U8)
+        hybrid_guard = False
+        if method == 'hybrid' and hasattr(self.ops, '_may_fuse'):
+            from ._lib import QBM_U8
+            hybrid_guard = bool(self.ops._may_fuse(self.k, QBM_U8))
         epoch_graph = self._epoch_graph   # (kept across calls: a later train_rbm on the same data replays from its first epoch)
         for epoch in range(epochs):
             # The two running sums of the epoch (:187 `epoch_error += batch_error.item()`, :191 `epoch_nll += nll.item()`)
@@ -333,12 +348,22 @@ class ClassificationRBM:
                 # step performs the epoch's gather into the dataset's buffers; the minibatches it yields are the same views in
                 # every epoch.
                 views = list(batches)
+                # everything a captured launch has baked into its arguments (the seed, the gradient buffer and
+                # the persistent chains are kernel arguments too)
                 key = (id(getattr(train_loader, 'last_views', None)), len(views), views[0][0].data_ptr() if views else 0,
                        views[0][1].data_ptr() if views else 0, getattr(train_loader, 'N', None), getattr(train_loader, 'batch_size', None),
                        views[-1][0].shape[0] if views else 0) + (
                     id(self._params()), float(self.learning_rate), float(self.sparse_constant), float(discriminative_factor), self.keep_grads,
-                    method, float(gen_factor), self.k, self.persistent)
-                if epoch_graph is None or epoch_graph[0] != key:
+                    method, float(gen_factor), self.k, self.persistent, int(self.seed), id(self._grads), self.data_parallel,
+                    0 if self._chain_v is None else self._chain_v.data_ptr(), 0 if self._chain_y is None else self._chain_y.data_ptr())
+                if epoch_graph is not None and epoch_graph[0] != key and epoch == 0:
+                    # other launches than the captured ones (another model state, data set or rule since the last call): this
+                    # epoch runs eagerly -- every workspace of the new shapes exists afterwards, nothing is allocated inside a
+                    # capture -- and the next one captures
+                    epoch_graph = self._epoch_graph = None
+                    batches = iter(views)
+                    views = None
+                if views is not None and (epoch_graph is None or epoch_graph[0] != key):
                     if self._draw_base is None:
                         self._draw_base = torch.zeros(2, dtype=torch.int64, device=self.device)
                     g = torch.cuda.CUDAGraph()
@@ -354,12 +379,13 @@ class ClassificationRBM:
                     # it, whatever the ops object's caches evict later)
                     keep = (dict(getattr(self.ops, '_cd_wss', {})), dict(getattr(self.ops, '_disc_wss', {})), views, sums, self._draw_base)
                     epoch_graph = self._epoch_graph = (key, g, keep)
-                if method == 'generative':   # this epoch's base of the draw ids / Philox rows, then the host counters move on
-                    self._draw_base.copy_(torch.tensor([self._draw_offset, self._rows_seen & 0xFFFFFFFF], dtype=torch.int64))
-                    self._draw_offset += len(views) * (3 * self.k + 1)
-                    self._rows_seen += len(views) * int(self._rank_rows if self._rank_rows else views[0][0].shape[0]) * self._world()
-                epoch_graph[1].replay()
-                batches = ()
+                if views is not None:
+                    if method == 'generative':   # this epoch's base of the draw ids / Philox rows, then the host counters move on
+                        self._draw_base.copy_(torch.tensor([self._draw_offset, self._rows_seen & 0xFFFFFFFF], dtype=torch.int64))
+                        self._draw_offset += len(views) * (3 * self.k + 1)
+                        self._rows_seen += len(views) * int(self._rank_rows if self._rank_rows else views[0][0].shape[0]) * self._world()
+                    epoch_graph[1].replay()
+                    batches = ()
             for batch, labels, onehot in batches:
                 if not resident:
                     batch = batch.view(len(batch), self.num_visible)  # flatten input data (:173)
@@ -372,8 +398,10 @@ class ClassificationRBM:
                     # p(y|x) is monitored under the parameters BEFORE the step's update, like the discriminative rule's report
                     self.contrastive_divergence_training(batch, labels, gen_factor, onehot=onehot, loss_acc=sums)
                 else:
-                    # Larochelle & Bengio hybrid objective: discriminative step + generative_factor * CD-k step
-                    self._disc_step(batch, labels, discriminative_factor, sums, False)
+                    # Larochelle & Bengio hybrid objective: discriminative step + generative_factor * CD-k step.  Where the CD
+                    # steps may go to a launch that can give up, the discriminative steps between them read the same status
+                    # word and are repeated in order with them
+                    self._disc_step(batch, labels, discriminative_factor, sums, False, guard_chain=hybrid_guard)
                     self.contrastive_divergence_training(batch, labels, gen_factor, onehot=onehot)
             if resident:
                 train_loader.epoch += 1

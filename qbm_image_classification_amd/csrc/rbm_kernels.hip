@@ -2157,12 +2157,14 @@ int launch_chain_fused(const qbm_rbm_params* P, const void* v0, int v0_dtype, co
 std::atomic<int> g_hgrad_fault_wg{-1}, g_hgrad_fault_kind{0};
 
 // Can the tail of this CD step -- last hidden phase + gradient (+ update) -- be ONE launch (k_hgrad)?
+// force: the shape test alone, whatever the process-wide switch says (qbm_rbm_cd_step_finish asks as the step asked, when
+// the switch may be off already; ADVICE round 3: the switch itself is not touched)
 bool hgrad_eligible(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void* v0, int v0_dtype, const float* y0, int B,
-                    const uint8_t* v1, const float* y1, const qbm_rbm_cd_workspace* ws, int fuse_update)
+                    const uint8_t* v1, const float* y1, const qbm_rbm_cd_workspace* ws, int fuse_update, bool force = false)
 {
     // mode 3 only: measured slower than the launch-per-phase tail on every shape tried -- kept as an
     // opt-in, with its tests, next to the numbers that say why
-    if (fused_chain_mode() != 3 || !device_has_8x32_cus() || !ws || !ws->sync || v0_dtype != QBM_U8 || ws->draw_base) return false;
+    if ((!force && fused_chain_mode() != 3) || !device_has_8x32_cus() || !ws || !ws->sync || v0_dtype != QBM_U8 || ws->draw_base) return false;
     const int V = P->V, H = P->H, C = P->C;
     const int nM = (B + 16 * H_MT - 1) / (16 * H_MT), nN = (H + 16 * H_NT - 1) / (16 * H_NT);
     // (B <= 256: one panel of 64 rows per K chain of the gradient -- its operands are requested in one go under the hidden phase)
@@ -2456,7 +2458,14 @@ int qbm_rbm_cd_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void*
     const float* y1 = (ws && chain_y) ? chain_y : (ws ? ws->yk : nullptr);
     const bool hg = B > 0 && batch_size > 0.f && v0 && y0 && ws && ws->ph0 && ws->phk && v1 && y1 &&
                     hgrad_eligible(P, G, v0, v0_dtype, y0, B, v1, y1, ws, fuse_update);
-    const uint32_t* hg_status = hg ? ws->sync + 512 : nullptr;
+    // FAIL-SAFE for the steps the fused launches do NOT take: wherever the switch would hand a step of this
+    // kind to a launch that can give up (the caller's record of pending steps, rbm_ops.HipRbmOps._may_fuse, asks the same
+    // question and ignores the shape as well), a step whose SHAPE is not eligible -- the short last minibatch of an epoch --
+    // runs one launch per phase with every storing launch reading the status word: behind a step that gave up it is a no-op
+    // like the eligible ones around it, and the host's replay repeats it in order.
+    const int mode = fused_chain_mode();
+    const bool may_fuse = ws && ws->sync && v0_dtype == QBM_U8 && !ws->draw_base && (mode >= 2 || (mode == 1 && k >= 2));
+    const uint32_t* hg_status = (hg || may_fuse) ? ws->sync + 512 : nullptr;
     // (the monitor's rows ride in the first k_visible launch as aux workgroups where that launch exists and B allows)
     const bool mon_vis = mon && visible_takes_monitor(B);
     if (int rc = cd_chain_impl(P, v0, v0_dtype, y0, B, k, seed, offset, row0, chain_v, chain_y, ws, stream, &fused,
@@ -2483,8 +2492,20 @@ int qbm_rbm_cd_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void*
     // word: a chain that gave up (or an earlier one on this workspace that did) never reaches gradients or parameters.
     return launch_grad(P->V, P->H, P->C, B, v0, v0_dtype, y0, ws->ph0, chain_v ? chain_v : ws->vk, QBM_U8,
                        chain_v ? chain_y : ws->yk, ws->phk, &g, fuse_update ? P->W : nullptr, fuse_update ? P : nullptr, lr,
-                       factor, batch_size, sparse_constant, (hipStream_t)stream, nullptr, fused ? ws->sync + 512 : nullptr, nullptr,
+                       factor, batch_size, sparse_constant, (hipStream_t)stream, nullptr, fused ? ws->sync + 512 : hg_status, nullptr,
                        mon ? ws->mon_rowloss : nullptr, mon ? ws->mon_loss_acc : nullptr);
+}
+
+int qbm_rbm_dp_step(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void* v0, int v0_dtype, const float* y0, int B,
+                    int k, uint64_t seed, uint64_t offset, uint32_t row0, uint8_t* chain_v, float* chain_y,
+                    const qbm_rbm_cd_workspace* ws, int apply_pending, float lr, float factor, float sparse_constant, void* stream)
+{
+    if (!G || !G->gW || !G->gb || !G->gd || !G->gU || !G->gc || !G->n_rows)
+        return fail(QBM_ERR_ARG, "dp_step: all gradient blocks and n_rows are required");
+    if (apply_pending)   // the update of the step before, from the all-reduced buffer (its row count read on the device)
+        if (int rc = qbm_rbm_update_dev(P, G, lr, factor, 0.f, G->n_rows, sparse_constant, nullptr, stream)) return rc;
+    return qbm_rbm_cd_step(P, G, v0, v0_dtype, y0, B, k, seed, offset, row0, chain_v, chain_y, ws, 0, lr, factor, 1.0f,
+                           sparse_constant, stream);
 }
 
 int qbm_rbm_cd_step_finish(const qbm_rbm_params* P, const qbm_rbm_grads* G, const void* v0, int v0_dtype, const float* y0, int B,
@@ -2497,9 +2518,8 @@ int qbm_rbm_cd_step_finish(const qbm_rbm_params* P, const qbm_rbm_grads* G, cons
     if (k < 1 || B <= 0 || !(batch_size > 0.f)) return fail(QBM_ERR_ARG, "cd_step_finish: bad k / B / batch_size");
     const uint8_t* v1 = chain_v ? chain_v : ws->vk;
     const float* y1 = chain_y ? chain_y : ws->yk;
-    const int prev = fused_chain_mode_ref().exchange(3);   // (eligibility is asked as the step asked it: the switch may be off by now)
-    const bool hg = v0 && y0 && ws->ph0 && ws->phk && v1 && y1 && hgrad_eligible(P, G, v0, v0_dtype, y0, B, v1, y1, ws, fuse_update);
-    fused_chain_mode_ref().store(prev);
+    // (eligibility is asked as the step asked it: the switch may be off by now)
+    const bool hg = v0 && y0 && ws->ph0 && ws->phk && v1 && y1 && hgrad_eligible(P, G, v0, v0_dtype, y0, B, v1, y1, ws, fuse_update, true);
     if (!hg) return fail(QBM_ERR_ARG, "cd_step_finish: not a step the fused tail takes");
     const bool mon = ws->mon_labels && ws->mon_pre && ws->mon_p && ws->mon_rowloss && ws->mon_loss_acc;
     for (int mode = 1; mode <= 2; ++mode)
@@ -2562,8 +2582,10 @@ int qbm_rbm_disc_step_ex(const qbm_rbm_params* P, const qbm_rbm_grads* G, const 
     //      (kind D workgroups, behind the strips: sigma(pre + U_c) is evaluated there once more rather than stored as a
     //      [B,C,H] array); every update fused
     if (int rc = launch_hidden(P, x, x_dtype, nullptr, B, ws->pre, nullptr, nullptr, 1, 0, 0, 0, st)) return rc;
+    // ws->status (hybrid training: the CD step behind this one may hand its chain to a launch that can give up): every
+    // storing launch reads it -- behind a step that gave up this one is a no-op and the host repeats it in order
 #define QBM_L(CM) \
-    launch_free_energy<CM>(ws->pre, P->U, P->c, neg_free_energy, p_y, B, P->H, P->C, labels, ws->diff, ws->rowloss, nullptr, st)
+    launch_free_energy<CM>(ws->pre, P->U, P->c, neg_free_energy, p_y, B, P->H, P->C, labels, ws->diff, ws->rowloss, ws->status, st)
     QBM_DISPATCH_CM(P->C, QBM_L);
 #undef QBM_L
     QBM_CHECK_LAUNCH("k_free_energy");
@@ -2577,12 +2599,12 @@ int qbm_rbm_disc_step_ex(const qbm_rbm_params* P, const qbm_rbm_grads* G, const 
     qbm_rbm_params aux{nullptr, nullptr, P->d, nullptr, nullptr, P->V, P->H, P->C};
     if (int rc = launch_grad(P->V, P->H, P->C, B, x, x_dtype, nullptr, ws->diff, nullptr, x_dtype, nullptr, nullptr, &g,
                              fuse ? P->W : nullptr, fuse ? &aux : nullptr, lr, factor, batch_size, sparse_constant, st,
-                             nullptr, nullptr, &dx))
+                             nullptr, ws->status, &dx))
         return rc;
     if (apply_update && !fuse) {
         g.gU = G->gU;
         g.gc = G->gc;
-        return qbm_rbm_update(P, &g, lr, factor, batch_size, sparse_constant, stream);
+        return qbm_rbm_update_dev(P, &g, lr, factor, batch_size, nullptr, sparse_constant, ws->status, stream);
     }
     return QBM_OK;
 }

@@ -428,7 +428,7 @@ class Disc_QBM:
         if hi > lo:
             self.ops.stats_diff(X[lo:hi], labels[lo:hi], mean_c, mean_u, D, H, buf)
             buf[-1] = self._nll_sum(mean_u, labels[lo:hi])
-        if world > 1:
+        if world > 1 or self._dp is True:   # (data_parallel=True on a one-rank group: the same code path, a one-rank all-reduce)
             import torch.distributed as dist
 
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)

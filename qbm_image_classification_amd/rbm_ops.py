@@ -190,13 +190,17 @@ class HipRbmOps:
 
     # ---- training steps -----------------------------------------------------------------------
     def disc_step(self, P: ParamSet, G: GradSet, x, labels, apply_update, fuse, lr, factor, batch_size, sparse,
-                  with_count=False, loss_acc=None, p_out=None):
+                  with_count=False, loss_acc=None, p_out=None, guard_chain=False, replay=None):
         """One discriminative_training pass (src/ClassificationRBM.py:101-140). -> p(y|x) [B,C]
         x: fp32, or uint8 {0,1} (binary inputs stay bytes: the uint8 kernels, same values).
         with_count: the gradient launch also stores its row count in G.count (the data-parallel path all-reduces it).
         loss_acc: float64 [2] device tensor; the step adds the minibatch's CrossEntropyLoss-on-probabilities (:142) and
         -log(p_y + 1e-8) mean (:188-191) to it -- the training loop's bookkeeping without a launch or a sync of its own.
-        p_out: where p(y|x) goes (default: a fresh tensor; `False`: a scratch buffer nobody reads)."""
+        p_out: where p(y|x) goes (default: a fresh tensor; `False`: a scratch buffer nobody reads).
+        guard_chain (hybrid training: discriminative and CD steps alternate on the same parameters): the step reads the status
+        word of the fused chain launches (include/qbm_hip.h: qbm_rbm_disc_workspace.status) -- behind a CD step that gave up it
+        stores nothing -- and is recorded with the pending CD steps, so that check_chain_status repeats it IN ORDER (`replay`:
+        what to call for that; default: this call again)."""
         x, xd = _state(x, self.device)
         if not (torch.is_tensor(labels) and labels.dtype == torch.int32 and labels.device == self.device
                 and labels.is_contiguous()):
@@ -213,6 +217,10 @@ class HipRbmOps:
                 hit = self._disc_wss[key] = (key, bufs, DiscWorkspace(ptr(bufs[0]), ptr(bufs[1]), ptr(bufs[2]), ptr(loss_acc)), loss_acc)
             self._disc_ws = hit
         ws = self._disc_ws[2]
+        guard = bool(guard_chain) and B > 0
+        if guard and len(self._pending) >= self.kPendingMax:   # between two steps: every recorded step is complete
+            self.check_chain_status()
+        ws.status = C.c_void_p(self._sync_buffer().data_ptr() + 4 * 512) if guard else None
         if p_out is None:
             p_out = torch.empty(B, P.C, dtype=torch.float32, device=self.device)
         elif p_out is False:
@@ -220,6 +228,10 @@ class HipRbmOps:
         check(self.lib.qbm_rbm_disc_step_ex(C.byref(P.struct()), C.byref(G.struct(with_gb=False, with_count=with_count)), ptr(x), xd,
                                             ptr(labels), B, ptr(p_out), None, C.byref(ws), int(apply_update), int(fuse), lr, factor,
                                             batch_size, sparse, current_stream()), "qbm_rbm_disc_step_ex")
+        if guard:
+            args = (P, G, x, labels, apply_update, fuse, lr, factor, batch_size, sparse)
+            self._pending.append((None, replay if replay is not None else
+                                  (lambda: self.disc_step(*args, with_count=with_count, loss_acc=loss_acc, p_out=p_out)), None))
         return p_out
 
     def cd_step(self, P: ParamSet, G: GradSet, v0, y0, k, seed, offset, row0, chain_v, chain_y, fuse, lr, factor,
@@ -267,8 +279,10 @@ class HipRbmOps:
             # applied) -- until the next look at the status word (check_chain_status: end of an epoch, or every kPendingMax steps)
             args = (P, G, v0, y0, k, seed, offset, row0, chain_v, chain_y, fuse, lr, factor, batch_size, sparse)
             pst, gst = P.struct(), G.struct(with_count=with_count)
+            keep_ws = ws   # (the closure holds the workspace's TENSORS, not only `cws`' raw pointers: the cache may evict the
+                           #  workspace of a short minibatch before check_chain_status runs)
 
-            def finish(rnd):
+            def finish(rnd, _keep=keep_ws):
                 check(self.lib.qbm_rbm_cd_step_finish(C.byref(pst), C.byref(gst), ptr(v0), vd, ptr(y0), B, k, seed, offset, row0,
                                                       ptr(chain_v), ptr(chain_y), C.byref(cws), int(fuse), lr, factor, batch_size,
                                                       sparse, rnd, current_stream()), "qbm_rbm_cd_step_finish")
@@ -336,7 +350,13 @@ class HipRbmOps:
         launch-per-phase path (same draws, same bits).  A fused tail that gave up (status 3 / 4) with the update inside may
         have applied the update of some column groups: that step is first FINISHED from its untouched workspace
         (qbm_rbm_cd_step_finish), then the later steps are repeated.  The process stays on the launch-per-phase path
-        (qbm_rbm_fused_chain_mode(0)) and a RuntimeWarning says so."""
+        (qbm_rbm_fused_chain_mode(0)) and a RuntimeWarning says so.
+        Steps of a shape the fused launches do not take (a short last minibatch) and the discriminative steps of hybrid
+        training read the same status word (include/qbm_hip.h: FAIL-SAFE), were no-ops alike and are repeated in order.
+        ONE case is not a bit-identical repeat: persistent chains (PCD) in a data-parallel group -- the ranks whose own launch
+        was fine have advanced their chains in the step another rank lost (only its UPDATE was skipped, through the -inf row
+        count) and in the steps after it, and the group's repeat starts from those chains: the parameters see the same
+        estimator on chains a few Gibbs steps further on.  (A snapshot of the chains per step would cost every step a copy.)"""
         if ws is not None:
             if len(ws) > 5 and ws[5] is not None:
                 st = int(ws[5][512].item())
@@ -371,7 +391,8 @@ class HipRbmOps:
         self._sync.zero_()
         warnings.warn(f"fused Gibbs chain kernel gave up (status {st}: {self._STATUS_TEXT.get(st, 'unknown')}); nothing was "
                       f"written since. " + ("Finished that step from its workspace; r" if finish is not None else "R") +
-                      f"epeating {len(pending) - first} step(s) with one launch per phase (same bits) and "
+                      f"epeating {len(pending) - first} step(s) with one launch per phase (same draws; same bits, except that "
+                      "the persistent chains of a data-parallel group's healthy ranks have moved on) and "
                       "staying on that path (qbm_rbm_fused_chain_mode(0)).", RuntimeWarning)
         for _, fn, _ in pending[first:]:
             fn()

@@ -77,6 +77,103 @@ def test_failed_chain_never_reaches_parameters_and_is_replayed(ops, oracle, fuse
     ops.check_chain_status()                                                      # nothing pending, nothing set: silent
 
 
+@pytest.mark.parametrize("path", ["fuse", "with_count"])
+def test_step_of_an_ineligible_shape_behind_a_failed_chain_is_a_noop_and_replayed_in_order(oracle, path):
+    """in the DEFAULT mode (1: the one-launch chain from k = 2 on) an epoch of full minibatches of 64
+    and a short last one of 36 -- a shape the chain kernel does not take (PneumoniaMNIST: 4708 % 64).  The status word is set
+    before the second step: the full minibatch behind it AND the short last one must change nothing (the short step runs one
+    launch per phase, every storing launch reading the word); check_chain_status then repeats steps 1, 2, 3 in order.
+    Parameters equal the oracle's after four steps bit for bit -- with the update fused into the gradient launch and on the
+    data-parallel form (row count -> update launch)."""
+    from qbm_image_classification_amd.rbm_ops import GradSet, HipRbmOps
+
+    ops = HipRbmOps("cuda:0")
+    prev = ops.fused_chain_mode(1)
+    try:
+        V, H, C, k = 784, 128, 2, 2
+        W, b, d, U, c = synth_params(V, H, C, 71)
+        P = P_of(ops, W, b, d, U, c)
+        G = GradSet(V, H, C, ops.device)
+        seed, lr, sparse = 5, 0.05, 0.001
+        sizes = [64, 64, 64, 36]
+        data = [synth_inputs(B, V, H, C, 60 + s) for s, B in enumerate(sizes)]
+        fuse = path == "fuse"
+
+        def step(s):
+            B = sizes[s]
+            v8, y = dev(ops, data[s][0].astype(np.uint8)), dev(ops, data[s][4])
+            off, row0 = 7 * s, 64 * s
+
+            def run():
+                ops.cd_step(P, G, v8, y, k, seed, off, row0, None, None, fuse, lr, 1.0, float(B), sparse, with_count=not fuse, replay=run)
+                if not fuse:
+                    ops.update(P, G, lr, 1.0, 0.0, sparse, count_dev=G.count)     # the data-parallel form: -inf rows = no-op
+            run()
+
+        step(0)
+        _oracle_step(oracle, W, b, d, U, c, data[0][0], data[0][4], k, seed, 0, 0, lr, 64, sparse)
+        assert_bitwise(P.W, W, "W after the first (healthy) step")
+        sync = ops._sync
+        sync[512:514] = torch.tensor([1, 7], dtype=torch.int32, device=sync.device)   # "step 1 (offset 7): a barrier timed out"
+        for s in (1, 2, 3):
+            step(s)
+        torch.cuda.synchronize()
+        for got, want, nm in ((P.W, W, "W"), (P.b, b, "b"), (P.d, d, "d"), (P.U, U, "U"), (P.c, c, "c")):
+            assert_bitwise(got, want, f"{nm} untouched behind a chain that gave up (the short last minibatch included)")
+        if not fuse:
+            assert float(G.count) == float("-inf")
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            ops.check_chain_status()
+        assert any("Repeating 3 step" in str(w.message) for w in rec), [str(w.message) for w in rec]
+        for s in (1, 2, 3):
+            _oracle_step(oracle, W, b, d, U, c, data[s][0], data[s][4], k, seed, 7 * s, 64 * s, lr, sizes[s], sparse)
+        for got, want, nm in ((P.W, W, "W"), (P.b, b, "b"), (P.d, d, "d"), (P.U, U, "U"), (P.c, c, "c")):
+            assert_bitwise(got, want, f"{nm} after the replay")
+    finally:
+        ops.fused_chain_mode(prev)
+
+
+def test_hybrid_discriminative_steps_behind_a_failed_chain_are_repeated_in_order(ops, oracle):
+    """hybrid training alternates discriminative and CD steps on the same parameters.  With the status word
+    set before the second CD step, the discriminative steps behind it must store nothing either (parameters, loss sums) and
+    be repeated IN ORDER with the CD steps: two objects -- one disturbed, one on the launch-per-phase path from the start --
+    end with the same bits."""
+    from qbm_image_classification_amd.classification_rbm import ClassificationRBM
+    from qbm_image_classification_amd.device_data import DeviceDataset
+
+    rs = np.random.RandomState(3)
+    V, H, C, N, B = 784, 128, 2, 4 * 64, 64
+    x = (rs.random_sample((N, V)) < 0.25).astype(np.uint8)
+    y = rs.randint(0, C, N)
+    outs = []
+    for disturbed in (True, False):
+        ops.fused_chain_mode(2 if disturbed else 0)
+        m = ClassificationRBM(V, H, 2, num_classes=C, learning_rate=0.05, seed=2, device="cuda:0")
+        ds = DeviceDataset(x, y, batch_size=B, num_classes=C, storage="u8", seed=4)
+        if disturbed:
+            orig, calls = m.contrastive_divergence_training, []
+
+            def spy(*a, **k):
+                if len(calls) == 1:      # in front of the second CD step: "its chain gave up" (word 513 = its draw offset)
+                    sync = m.ops._sync_buffer()
+                    sync[512:514] = torch.tensor([1, m._draw_offset], dtype=torch.int32, device=sync.device)
+                calls.append(1)
+                return orig(*a, **k)
+
+            m.contrastive_divergence_training = spy
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            loss, _, nll = m.train_rbm(ds, epochs=1, method="hybrid", generative_factor=0.1)
+        if disturbed:
+            # 4 minibatches: CD steps 2..4 and the discriminative steps 3, 4 (step 2's ran in front of the lost CD step)
+            assert any("Repeating 5 step" in str(w.message) for w in rec), [str(w.message) for w in rec]
+        outs.append((loss, nll, [getattr(m, nm).clone() for nm in ("weights", "visible_bias", "hidden_bias", "class_weights", "class_bias")]))
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1]
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert torch.equal(a, b)
+
+
 def test_caller_owned_workspace_with_status_set(ops):
     """A caller-owned workspace whose status word is set: the chain and the gradient launch do nothing (the row-count slot
     reads -inf, which turns a data-parallel update into a no-op on every rank), qbm_rbm_update_dev honours both guards,
