@@ -55,9 +55,14 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    import gc
+
     import torch
     import torch.distributed as dist
 
+    # no cycle collection in this short process: the collector may otherwise run inside a stream capture (destroying a device
+    # object there is not a legal call) or put a pause into the timed region
+    gc.disable()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -14,6 +14,8 @@ to probabilities (Q1, :142); roc_auc_score is computed on hard predictions (Q4, 
 """
 from __future__ import annotations
 
+import functools
+import gc
 import os
 
 import numpy as np
@@ -190,18 +192,21 @@ class ClassificationRBM:
         self.visible_bias_grad = 0  # :138
         lr, sp = float(self.learning_rate), float(self.sparse_constant)
         G, f, bs = self._grads, float(factor), float(batch_size)
+        # (`step` must not refer to itself: a function that closes over itself is a reference cycle, and everything it holds --
+        # device tensors, the model with its captured hipGraph -- then lives until the cycle collector runs, possibly in the
+        # middle of another stream capture)
         if self.data_parallel:
-            def step(guard=guard_chain):
+            def step(guard):
                 p = self.ops.disc_step(P, G, input_data, class_label, False, False, lr, f, bs, sp, with_count=True, loss_acc=loss_acc,
-                                       p_out=p_out, **(dict(guard_chain=True, replay=lambda: step(False)) if guard else {}))
+                                       p_out=p_out, **(dict(guard_chain=True, replay=functools.partial(step, False)) if guard else {}))
                 self._allreduce_grads()
                 self.ops.update(P, G, lr, f, 0.0, sp, with_gb=False, count_dev=G.count)
                 return p
         else:
-            def step(guard=guard_chain):
+            def step(guard):
                 return self.ops.disc_step(P, G, input_data, class_label, True, not self.keep_grads, lr, f, bs, sp, loss_acc=loss_acc,
-                                          p_out=p_out, **(dict(guard_chain=True, replay=lambda: step(False)) if guard else {}))
-        return step()
+                                          p_out=p_out, **(dict(guard_chain=True, replay=functools.partial(step, False)) if guard else {}))
+        return step(guard_chain)
 
     def discriminative_training(self, input_data, class_label, factor=1):
         """src/ClassificationRBM.py:101-146 -> (error, predicted, class_probabilities)"""
@@ -260,22 +265,23 @@ class ClassificationRBM:
         self.visible_bias_grad = self._grads.gb
         G, k, seed, f, bs = self._grads, self.k, self.seed, float(factor), float(batch_size)
         # `step` is also what HipRbmOps.check_chain_status calls to repeat this minibatch on the launch-per-phase path should
-        # its one-launch chain have given up (its gradient and update launches were then no-ops)
+        # its one-launch chain have given up (its gradient and update launches were then no-ops): handed over as
+        # functools.partial(step, None) -- a repeat records nothing itself
         if self.data_parallel:
-            def step():
-                self.ops.cd_step(P, G, v0, y0, k, seed, offset, row0, cv, cy, False, lr, f, bs, sp, with_count=True, replay=step,
+            def step(replay):
+                self.ops.cd_step(P, G, v0, y0, k, seed, offset, row0, cv, cy, False, lr, f, bs, sp, with_count=True, replay=replay,
                                  monitor=monitor, draw_base=draw_base)
                 self._allreduce_grads()
                 self.ops.update(P, G, lr, f, 0.0, sp, count_dev=G.count)   # global batch size read on the device
         elif self.keep_grads:
-            def step():
-                self.ops.cd_step(P, G, v0, y0, k, seed, offset, row0, cv, cy, False, lr, f, bs, sp, replay=step, monitor=monitor)
+            def step(replay):
+                self.ops.cd_step(P, G, v0, y0, k, seed, offset, row0, cv, cy, False, lr, f, bs, sp, replay=replay, monitor=monitor)
                 self.ops.update(P, G, lr, f, bs, sp, guard_chain=True)
         else:  # every update fused into the gradient launch
-            def step():
-                self.ops.cd_step(P, G, v0, y0, k, seed, offset, row0, cv, cy, True, lr, f, bs, sp, replay=step, monitor=monitor,
+            def step(replay):
+                self.ops.cd_step(P, G, v0, y0, k, seed, offset, row0, cv, cy, True, lr, f, bs, sp, replay=replay, monitor=monitor,
                                  draw_base=draw_base)
-        step()
+        step(functools.partial(step, None))
         # Philox rows advance by the NOMINAL global minibatch (the loader's batch_size x ranks; a short last minibatch
         # included): known on the host of every rank without asking the device for the all-reduced row count
         if _rel is None:
@@ -368,13 +374,24 @@ class ClassificationRBM:
                         self._draw_base = torch.zeros(2, dtype=torch.int64, device=self.device)
                     g = torch.cuda.CUDAGraph()
                     torch.cuda.synchronize()
-                    with torch.cuda.graph(g):
-                        for i, (batch, labels, onehot) in enumerate(views):
-                            if method == 'discriminative':
-                                self._disc_step(batch, labels, discriminative_factor, sums, False)
-                            else:
-                                self.contrastive_divergence_training(batch, labels, gen_factor, onehot=onehot, loss_acc=sums,
-                                                                     _rel=(i, self._draw_base))
+                    # No cycle collection while the stream is capturing: the collector may run at any allocation, and what it
+                    # finds may be an older model's hipGraph or device tensors, whose destruction is not a legal call during a
+                    # capture (torch.cuda.graph no longer collects by itself) -- found as an abort of the GPU test process in
+                    # round 4.  Collect first, then keep the collector off until the capture has ended.
+                    gc.collect()
+                    gc_was_on = gc.isenabled()
+                    gc.disable()
+                    try:
+                        with torch.cuda.graph(g):
+                            for i, (batch, labels, onehot) in enumerate(views):
+                                if method == 'discriminative':
+                                    self._disc_step(batch, labels, discriminative_factor, sums, False)
+                                else:
+                                    self.contrastive_divergence_training(batch, labels, gen_factor, onehot=onehot, loss_acc=sums,
+                                                                         _rel=(i, self._draw_base))
+                    finally:
+                        if gc_was_on:
+                            gc.enable()
                     # (the graph's launches hold the addresses of the step's scratch: the workspaces of the moment are kept alive with
                     # it, whatever the ops object's caches evict later)
                     keep = (dict(getattr(self.ops, '_cd_wss', {})), dict(getattr(self.ops, '_disc_wss', {})), views, sums, self._draw_base)

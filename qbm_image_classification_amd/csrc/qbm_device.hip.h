@@ -143,9 +143,22 @@ __device__ __forceinline__ float wave_butterfly_sum(float p)
     return p;
 }
 
-// [Q] length of one of the NQ chains a contraction of length K is cut into: roundup16(ceil(K / NQ)) -- a whole number of
-// 16-k staging pieces.  NQ = 4 ("quarters": the gradient, contracted over the batch) or 8 (the conditionals).
-__host__ __device__ __forceinline__ int chain_len(int K, int nq) { return (((K + nq - 1) / nq) + 15) / 16 * 16; }
+// [Q] the NQ chains a contraction of length K is cut into: WHOLE 16-k staging pieces, dealt as evenly as they go -- with
+// P = ceil(K / 16) pieces every chain takes P / NQ of them and the LAST P % NQ chains one more (K = 784, NQ = 8: 49 pieces =
+// 6,6,6,6,6,6,6,7; round 3 cut K into NQ chains of roundup16(ceil(K / NQ)) = 7,7,7,7,7,7,7,0 pieces: one wavefront of eight
+// idle and the critical SIMD a piece longer).  Chain q covers k in [k0, k1).  NQ = 4 ("quarters": the gradient, contracted over
+// the batch) or 8 (the conditionals).  Restated in oracle/qbm_oracle.c::chain_range.
+__host__ __device__ __forceinline__ void chain_range(int K, int nq, int q, int& k0, int& k1)
+{
+    const int P = (K + 15) >> 4, base = P / nq, rem = P - base * nq;
+    const int extra = q - (nq - rem);                  // chains in front of q that hold one piece more (if positive)
+    const int p0 = q * base + (extra > 0 ? extra : 0);
+    const int np = base + (q >= nq - rem ? 1 : 0);
+    k0 = 16 * p0 < K ? 16 * p0 : K;
+    k1 = 16 * (p0 + np) < K ? 16 * (p0 + np) : K;
+}
+// length of the longest chain (a whole number of pieces): what panels and LDS images are sized for
+__host__ __device__ __forceinline__ int chain_len(int K, int nq) { return ((((K + 15) >> 4) + nq - 1) / nq) * 16; }
 __host__ __device__ __forceinline__ int quarter_len(int K) { return chain_len(K, 4); }
 
 }  // namespace qbm

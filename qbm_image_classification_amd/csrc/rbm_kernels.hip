@@ -48,6 +48,15 @@ constexpr int V_MT = QBM_V_MT, V_NT = 1;
 // round too: 64 x 16 strips for the two-phase form at 784 x 512 cost 9.6 instead of 8.5 us per launch (every data tile is
 // staged twice as often), B = 2048: 135 instead of 126 us per step.
 constexpr int G_MT = 4;
+// Round 4: 112 x 16 strips (MT = 7, NT = 1) for the two-phase form where they tile V exactly and fill more CUs than the 64 x 32
+// ones: 784 = 7 x 112, so 784 x 512 is 7 x 32 = 224 full workgroups -- the 64 x 32 strips cut 784 rows into 12 1/4: 13 x 16 = 208
+// workgroups on 256 CUs, the 13th row strip a quarter full (94 % useful MFMAs); per workgroup 7/8 of the MFMA work and 88 KB
+// instead of 96 KB staged.  The seven row tiles of a strip share one merged uint8 image (seven 16-byte slots per k: 112-byte
+// rows, conflict-free for ds_read_u8), filled by seven 1-KiB transfers per 64 k.
+constexpr int G_MT7 = 7;
+#ifndef QBM_GRAD_112   // diagnostic builds: 0 = never take the 112 x 16 strips (A/B timing)
+#define QBM_GRAD_112 1
+#endif
 
 // class-count buckets for the kernels that keep one register (or one float4) per class
 #define QBM_DISPATCH_CM(C, MACRO)                   \
@@ -1065,9 +1074,9 @@ __device__ __forceinline__ void loss_block(const GradArgs& a, char* lds_raw)
     float* rl = reinterpret_cast<float*>(lds_raw);   // [tile][2], then 8 partial sums
     const int B = a.B, n = (int)blockDim.x, tid = (int)threadIdx.x;
     float* part = rl + 2 * n;
-    const int Kq = quarter_len(B);
     const int q = tid & 3, k = (tid >> 2) & 1;        // threads 0..7: (quarter q, column k)
-    const int lo = q * Kq, hi = min(B, lo + Kq);
+    int lo, hi;
+    chain_range(B, 4, q, lo, hi);
     float acc = 0.f;
     for (int r0 = 0; r0 < B; r0 += n) {
         const int nr = min(n, B - r0);
@@ -1111,13 +1120,13 @@ __device__ __forceinline__ void disc_class_block1(const GradArgs& a, int c, int 
     const int tid = (int)threadIdx.x;
     const int col = tid & 15, slot = tid >> 4;
     const int j = jb * 16 + col, jj = min(j, H - 1);
-    const int Kq = quarter_len(B);
     const float u = a.Up[(long)c * H + jj];
     const bool with_loss = c == 0 && jb == 0 && a.rowloss != nullptr;
     // roles in the summation stage: threads 0..63 chain A (o * p), 64..127 chain B (onehot * o), 128..143 the four side sums
     const int role = tid < 64 ? 0 : tid < 128 ? 1 : tid < 144 ? 2 + ((tid - 128) >> 2) : 6;
     const int q = role <= 1 ? (tid >> 4) & 3 : tid & 3;
-    const int lo = q * Kq, hi = min(B, lo + Kq);
+    int lo, hi;
+    chain_range(B, 4, q, lo, hi);
     float acc = 0.f;
     for (int r0 = 0; r0 < B; r0 += 256) {
         const int nr = min(256, B - r0);
@@ -1286,20 +1295,22 @@ __device__ __forceinline__ void grad_w_strip_par(const GradArgs& a, int m0, int 
     using SO = StripOut<MT, NT>;
     static_assert(SO::NP == 2 || SO::NP == 1, "the two groups share the epilogue");
     char* lds = lds_all + (size_t)grp * a.lds_group;
-    const ViewCContig P0{a.P0, a.H, a.H, a.B}, P1{a.P1, a.H, a.H, a.B};
-    const ViewCContigU8 D0{reinterpret_cast<const uint8_t*>(a.A0), a.V, a.V, a.B}, D1{reinterpret_cast<const uint8_t*>(a.A1), a.V, a.V, a.B};
     const bool first = grp == 0;
+    // ONE instantiation of the contraction for both groups: the phase's operands are picked by scalar selects (two calls --
+    // one per phase behind a branch -- kept the views, descriptors and walks of BOTH phases live across the branch: 21 spilled
+    // SGPRs in the benchmark's variant, and twice the code for the instruction cache of a cold start)
+    const ViewCContig Pm{first ? a.P0 : a.P1, a.H, a.H, a.B};
+    const ViewCContigU8 Dm{reinterpret_cast<const uint8_t*>(first ? a.A0 : a.A1), a.V, a.V, a.B};
     const int t = (int)threadIdx.x & 255;
     const bool mine_to_finish = SO::NP == 2 || (t >> 7) == grp;      // (NP == 1) do I finish my output, or hand it over?
     constexpr int kOp1 = SO::NP == 2 ? 1 : 0;                        // group 1's output among a thread's
     float4 w_old = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int my_op = first ? 0 : kOp1;
     auto pre0 = [&]() {
-        if (mine_to_finish) w_old = first ? grad_w_tile<SO>(a, m0, n0, 0) : grad_w_tile<SO>(a, m0, n0, kOp1);
+        if (mine_to_finish) w_old = grad_w_tile<SO>(a, m0, n0, my_op);
     };
     QBM_STAMP(11);
-    SO mine;
-    if (first) mine = strip_mma<MT, NT, FAST, FAST>(D0, P0, m0, n0, a.B, lds, a.KP, pre0);
-    else mine = strip_mma<MT, NT, FAST, FAST>(D1, P1, m0, n0, a.B, lds, a.KP, pre0, NoPre{}, 5);
+    const SO mine = strip_mma<MT, NT, FAST, FAST>(Dm, Pm, m0, n0, a.B, lds, a.KP, pre0, NoPre{}, first ? 0 : 5);
     float4* x = reinterpret_cast<float4*>(lds_all);   // every thread has left strip_mma: the staging regions are free
     if constexpr (SO::NP == 2) {
         // group 0 finishes output 0 and needs phase 1's output 0; group 1 finishes output 1 and needs phase 0's output 1
@@ -1323,11 +1334,13 @@ __device__ __forceinline__ void grad_w_strip_par(const GradArgs& a, int m0, int 
 // PAR (both data operands uint8: the Gibbs states of the CD-k / PCD step): 512 threads, the phases side by side.
 // Otherwise (fp32 data: twice the staging bytes, two regions do not fit the LDS): 256 threads, phase after phase.
 // ONE (the discriminative step): phase 0 only -- gW = A0^T.P0 -- and the kind D workgroups behind the strips; 256 threads.
-template <class T0, class T1, bool FAST, bool PAR, bool ONE, int NT>
+// MT x NT: the W strips' tiles (64 x 32, 64 x 16 or 112 x 16: see G_MT); UNT: tiles of 16 hidden columns per workgroup of kind U
+// (and of 16 classes per workgroup of kind C) -- NT, or 2 beside the 112 x 16 strips so that the whole launch stays one round
+template <class T0, class T1, bool FAST, bool PAR, bool ONE, int NT, int MT = G_MT>
 __global__ __launch_bounds__(PAR ? 512 : 256) void k_grad(GradArgs a)
 {
     static_assert(!(PAR && ONE), "the one-phase form takes the 256-thread kernel");
-    constexpr int MT = G_MT;
+    constexpr int UNT = MT == G_MT7 ? 2 : NT;
     extern __shared__ __attribute__((aligned(16))) char lds_all[];
     QBM_STAMP(10);
     asm volatile("" ::"s"(a.A0), "s"(a.P0), "s"(a.A1), "s"(a.P1), "s"(a.gW), "s"(a.W), "s"(a.B), "s"(a.V), "s"(a.H), "s"(a.C),
@@ -1360,12 +1373,12 @@ __global__ __launch_bounds__(PAR ? 512 : 256) void k_grad(GradArgs a)
         else                                     \
             for (int op = 0; op < SOT::NP; ++op) o1.sum[op] = make_float4(0.f, 0.f, 0.f, 0.f);   \
     }
-    if (blk < a.nU) {  // class-weight rows and the hidden-bias row (C + 1 <= 16 rows: one row tile) x 16*NT hidden columns
-        const int n0 = blk * 16 * NT;
+    if (blk < a.nU) {  // class-weight rows and the hidden-bias row (C + 1 <= 16 rows: one row tile) x 16*UNT hidden columns
+        const int n0 = blk * 16 * UNT;
         const ViewAugY Y0{a.Y0, a.C}, Y1{a.Y1, a.C};
-        using SOT = StripOut<1, NT>;
-        QBM_TWO_PHASES(SOT, (strip_mma<1, NT, false, FAST>(Y0, P0, 0, n0, a.B, lds, a.KP)),
-                       (strip_mma<1, NT, false, FAST>(Y1, P1, 0, n0, a.B, lds, a.KP)))
+        using SOT = StripOut<1, UNT>;
+        QBM_TWO_PHASES(SOT, (strip_mma<1, UNT, false, FAST>(Y0, P0, 0, n0, a.B, lds, a.KP)),
+                       (strip_mma<1, UNT, false, FAST>(Y1, P1, 0, n0, a.B, lds, a.KP)))
         grad_epi_u(a, n0, o0, o1);
         return;
     }
@@ -1380,13 +1393,13 @@ __global__ __launch_bounds__(PAR ? 512 : 256) void k_grad(GradArgs a)
         return;
     }
     blk -= a.nB;
-    if (blk < a.nC) {  // class bias: column sums of the labels = ones^T . Y, 16*NT classes per workgroup
-        const int n0 = blk * 16 * NT;
+    if (blk < a.nC) {  // class bias: column sums of the labels = ones^T . Y, 16*UNT classes per workgroup
+        const int n0 = blk * 16 * UNT;
         const ViewOnesRow ones;
         const ViewCContig Y0{a.Y0, a.C, a.C, a.B}, Y1{a.Y1, a.C, a.C, a.B};
-        using SOT = StripOut<1, NT>;
-        QBM_TWO_PHASES(SOT, (strip_mma<1, NT, false, false>(ones, Y0, 0, n0, a.B, lds, a.KP)),
-                       (strip_mma<1, NT, false, false>(ones, Y1, 0, n0, a.B, lds, a.KP)))
+        using SOT = StripOut<1, UNT>;
+        QBM_TWO_PHASES(SOT, (strip_mma<1, UNT, false, false>(ones, Y0, 0, n0, a.B, lds, a.KP)),
+                       (strip_mma<1, UNT, false, false>(ones, Y1, 0, n0, a.B, lds, a.KP)))
         grad_epi_c(a, n0, o0, o1);
         return;
     }
@@ -1976,13 +1989,13 @@ struct DiscExtras {
     float* dgU; float* dgc; float* duU; float* duc; float* dub;
 };
 
-template <class T0, class T1, bool PAR, int NT>
+template <class T0, class T1, bool PAR, int NT, int MT = G_MT>
 int launch_grad_t(int V, int H, int C, int B, const void* A0, const float* Y0, const float* P0, const void* A1,
                   const float* Y1, const float* P1, const qbm_rbm_grads* G, float* W_fused, const qbm_rbm_params* aux_fused,
                   float lr, float factor, float bs, float sparse, hipStream_t st, const float* gU_sub, const uint32_t* status,
                   const DiscExtras* dx, const float* mon_rowloss, double* mon_loss_acc)
 {
-    constexpr int MT = G_MT;
+    constexpr int UNT = MT == G_MT7 ? 2 : NT;   // tiles per workgroup of kinds U / C (k_grad)
     const int nM = (V + 16 * MT - 1) / (16 * MT), nN = (H + 16 * NT - 1) / (16 * NT);
     const bool want_b = G->gb || (aux_fused && aux_fused->b);
     const bool want_c = G->gc || (aux_fused && aux_fused->c);
@@ -1990,7 +2003,7 @@ int launch_grad_t(int V, int H, int C, int B, const void* A0, const float* Y0, c
                aux_fused ? aux_fused->b : nullptr, aux_fused ? aux_fused->d : nullptr,
                aux_fused ? aux_fused->U : nullptr, aux_fused ? aux_fused->c : nullptr,
                lr, factor, bs, sparse, B, V, H, C, panel_for<MT, NT, 4>(B),
-               nN, want_b ? nM : 0, want_c ? (C + 16 * NT - 1) / (16 * NT) : 0,
+               (H + 16 * UNT - 1) / (16 * UNT), want_b ? nM : 0, want_c ? (C + 16 * UNT - 1) / (16 * UNT) : 0,
                (H % 4 == 0) && (!G->gW || aligned16(G->gW)) && (!W_fused || aligned16(W_fused)), gU_sub, 0, 0, 0, div_magic(nM), status, G->n_rows,
                0, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (mon_rowloss && mon_loss_acc) { a.nL = 1; a.rowloss = mon_rowloss; a.loss_acc = mon_loss_acc; }
@@ -2011,7 +2024,7 @@ int launch_grad_t(int V, int H, int C, int B, const void* A0, const float* Y0, c
         // rows / ones operands of kinds U, C are synthesised fp32 single-tile operands); the strips the groups swap
         // afterwards (2 x NP float4 per thread of a group) must fit as well
         size_t g = strip_lds_bytes<MT, NT, 1>(a.KP);
-        if (g < (size_t)strip_lds_bytes<1, NT, 4>(a.KP)) g = strip_lds_bytes<1, NT, 4>(a.KP);
+        if (g < (size_t)strip_lds_bytes<1, UNT, 4>(a.KP)) g = strip_lds_bytes<1, UNT, 4>(a.KP);
         if (g < (size_t)strip_lds_bytes<MT, 1, 1>(a.KP)) g = strip_lds_bytes<MT, 1, 1>(a.KP);
         a.lds_group = (int)g;
         lds = 2 * g;
@@ -2021,7 +2034,7 @@ int launch_grad_t(int V, int H, int C, int B, const void* A0, const float* Y0, c
     } else {
         constexpr int ASZ = sizeof(T0) == 1 && sizeof(T1) == 1 ? 1 : 4;   // an fp32 operand sets the budget
         lds = strip_lds_bytes<MT, NT, ASZ>(a.KP);
-        if (lds < (size_t)strip_lds_bytes<1, NT, 4>(a.KP)) lds = strip_lds_bytes<1, NT, 4>(a.KP);   // kinds U, C: synthesised fp32 tile
+        if (lds < (size_t)strip_lds_bytes<1, UNT, 4>(a.KP)) lds = strip_lds_bytes<1, UNT, 4>(a.KP);   // kinds U, C: synthesised fp32 tile
         if (lds < 24576) lds = 24576;                                                                // kind D / kind L: their LDS arrays
     }
     if (dx) {
@@ -2038,10 +2051,10 @@ int launch_grad_t(int V, int H, int C, int B, const void* A0, const float* Y0, c
         a.nD = C * ((nJ + a.dW - 1) / a.dW);
     }
     const int grid = a.nU + a.nB + a.nC + nM * nN + a.nD + a.nL;
-#define QBM_LAUNCH(F, ONE)                                                                                     \
-    {                                                                                                           \
-        if (int rc = set_lds(k_grad<T0, T1, F, PAR, ONE, NT>, lds)) return rc;                                  \
-        hipLaunchKernelGGL((k_grad<T0, T1, F, PAR, ONE, NT>), dim3(grid), dim3(PAR ? 512 : 256), lds, st, a);   \
+#define QBM_LAUNCH(F, ONE)                                                                                         \
+    {                                                                                                               \
+        if (int rc = set_lds(k_grad<T0, T1, F, PAR, ONE, NT, MT>, lds)) return rc;                                  \
+        hipLaunchKernelGGL((k_grad<T0, T1, F, PAR, ONE, NT, MT>), dim3(grid), dim3(PAR ? 512 : 256), lds, st, a);   \
     }
     if constexpr (PAR) {
         if (fast) QBM_LAUNCH(true, false) else QBM_LAUNCH(false, false)
@@ -2069,9 +2082,19 @@ int launch_grad(int V, int H, int C, int B, const void* A0, int d0, const float*
     if (C + 1 > 16) return fail(QBM_ERR_ARG, "two_phase_grad: at most 15 classes (class rows + the bias row share one 16-row tile)");
 #define QBM_G(T0, T1, PAR, NT) launch_grad_t<T0, T1, PAR, NT>(V, H, C, B, A0, Y0, P0, A1, Y1, P1, G, W_fused, aux_fused, lr, factor, bs, sparse, st, gU_sub, status, dx, mon_rowloss, mon_loss_acc)
     // strips of 64 x 16 for the one-phase form and where 64 x 32 strips would leave half of the CUs idle (see G_MT)
-    const bool narrow = dx || !P1 || ((V + 16 * G_MT - 1) / (16 * G_MT)) * ((H + 31) / 32) < 128;
+    const int wide = ((V + 16 * G_MT - 1) / (16 * G_MT)) * ((H + 31) / 32);
+    const bool narrow = dx || !P1 || wide < 128;
     if (d0 == QBM_U8 && d1 == QBM_U8) {
-        if (P1 && !dx) return narrow ? QBM_G(uint8_t, uint8_t, true, 1) : QBM_G(uint8_t, uint8_t, true, 2);
+        if (P1 && !dx) {
+            // 112 x 16 strips where they tile V exactly, fill more CUs than the 64 x 32 ones and the launch -- strips, kinds U
+            // (32 columns each), B, C, L -- is still ONE round of one workgroup per CU (see G_MT7)
+            const int tall = (V / (16 * G_MT7)) * ((H + 15) / 16);
+            if (QBM_GRAD_112 && !narrow && V % (16 * G_MT7) == 0 && tall > wide &&
+                tall + (H + 31) / 32 + V / (16 * G_MT7) + (C + 31) / 32 + 1 <= 256)
+                return launch_grad_t<uint8_t, uint8_t, true, 1, G_MT7>(V, H, C, B, A0, Y0, P0, A1, Y1, P1, G, W_fused, aux_fused, lr, factor,
+                                                                       bs, sparse, st, gU_sub, status, dx, mon_rowloss, mon_loss_acc);
+            return narrow ? QBM_G(uint8_t, uint8_t, true, 1) : QBM_G(uint8_t, uint8_t, true, 2);
+        }
         return QBM_G(uint8_t, uint8_t, false, 1);
     }
     if (d0 == QBM_U8) return QBM_G(uint8_t, float, false, 2);

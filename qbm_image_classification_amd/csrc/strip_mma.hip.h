@@ -224,13 +224,15 @@ struct ViewCContigU8 {
         const int k = kb + lane;
         return DmaLane{c0 < cols ? (unsigned)(k * (int)ld + c0) : kOOB, (unsigned)(64 * ld), k, 64};
     }
-    // transfer instruction j (0..TILES-1) of a quad, all TILES adjacent 16-wide tiles from column c0 on: lane L takes
-    // k = kb + (64/TILES)*j + L/TILES of tile L % TILES
+    // transfer instruction j (0..TILES-1) of a quad, all TILES adjacent 16-wide tiles from column c0 on: the quad's image is
+    // 64 k x TILES slots of 16 bytes = TILES transfers of 64 slots; lane L of transfer j fills slot s = 64 j + L, i.e.
+    // k = kb + s / TILES of tile s % TILES (TILES = 1, 2, 4: k = kb + (64 / TILES) j + L / TILES of tile L % TILES)
     template <int TILES>
     __device__ __forceinline__ DmaLane lane0_tiles(int c0, int kb, int lane, int j) const
     {
-        static_assert(TILES == 1 || TILES == 2 || TILES == 4, "a k row of TILES * 16 bytes: at 8 tiles the rows k and k + 1 that one ds_read_u8 reads would meet on the same banks");
-        const int k = kb + (64 / TILES) * j + lane / TILES, c = c0 + 16 * (lane % TILES);
+        static_assert(TILES == 1 || TILES == 2 || TILES == 4 || TILES == 7, "a k row of TILES * 16 bytes: at 8 tiles the rows k and k + 1 that one ds_read_u8 reads would meet on the same banks (7: 112-byte rows, conflict-free)");
+        const int s = 64 * j + lane;
+        const int k = kb + s / TILES, c = c0 + 16 * (s % TILES);
         return DmaLane{c < cols ? (unsigned)(k * (int)ld + c) : kOOB, (unsigned)(64 * ld), k, 64};
     }
     __device__ __forceinline__ uint4 get(int c0, int kb, int kend, int slot) const
@@ -423,7 +425,9 @@ template <int NT, int NQ = 4>
 __device__ __forceinline__ int chain_transfers_b(int K, int KP)
 {
     const int q = __builtin_amdgcn_readfirstlane(((int)threadIdx.x & (64 * NQ - 1)) >> 6);
-    const int Kq = chain_len(K, NQ), klen = max(0, min(min(K, (q + 1) * Kq) - q * Kq, KP));
+    int k0, k1;
+    chain_range(K, NQ, q, k0, k1);
+    const int klen = max(0, min(k1 - k0, KP));
     return NT * ((klen + 15) >> 4);
 }
 template <int MT, int NT, bool FAST_A, bool FAST_B, int CPT = 4, int NQ = 4, bool KPERM = false, int AUX_A = 0, int AUX_B = 0,
@@ -453,9 +457,8 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
     const int tid = threadIdx.x & (64 * NQ - 1);   // the thread's index inside its group of NQ wavefronts
     const int lane = tid & 63;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave id == K chain (wave-uniform, SGPR)
-    const int Kq = chain_len(K, NQ);
-    const int kq0 = q * Kq;
-    const int kend = min(K, kq0 + Kq);
+    int kq0, kend;                                  // this wavefront's chain: k in [kq0, kend), whole pieces ([Q])
+    chain_range(K, NQ, q, kq0, kend);
     const int wave_bytes = ldsB ? strip_wave_bytes_a<MT, NT, ASZ>(KP) : strip_wave_bytes<MT, NT, ASZ>(KP);
     char* img = lds + (size_t)q * wave_bytes;
     char* imgA = img;                              // MT tiles of 16*KP*ASZ bytes
@@ -719,7 +722,7 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
         if (ahead >= 2 && qbm_diag != 4 && quads > 1) issue_quad(1);
         QBM_STAMP(stamp0 + 1);
         pre(ahead >= 2 ? quad_dmas(1) : 0);
-        for (int kb = kq0; kb < kq0 + Kq; kb += KP) {
+        for (int kb = kq0; kb < kend; kb += KP) {
             if (kb != kq0) {
                 open_panel(kb);
                 if (qbm_diag != 4 && quads > 0) issue_quad(0);
@@ -749,7 +752,7 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
         // ---- at least one operand goes through registers (unaligned / ragged / synthesised)
         pre0();
         pre(0);
-        for (int kb = kq0; kb < kq0 + Kq; kb += KP) {
+        for (int kb = kq0; kb < kend; kb += KP) {
             const int klen = max(0, min(kend - kb, KP));
             const int pieces = (klen + 15) >> 4;
             const int quads = (pieces + 3) >> 2;
