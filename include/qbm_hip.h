@@ -327,6 +327,18 @@ QBM_API long qbm_kcenter_workspace_bytes(int N, int n_seeds);
 QBM_API int qbm_kcenter_greedy(const float* embT, int N, int D, const int32_t* seeds_host, int n_seeds, int n_picks,
                                int32_t* picks, uint8_t* selected, void* workspace, void* stream);
 
+/* The same selection in ONE launch (round 4): 256 persistent workgroups keep their rows of the embedding matrix in LDS and
+ * exchange one 8-byte granule per pick, inside an XCD through its L2 and across XCDs write-through (csrc/coreset_kernels.hip).
+ * emb is the matrix as stored, [N,D] fp32 ROW-major on the device (D a multiple of 4, 16-byte aligned); seeds_dev (n_seeds >= 1,
+ * int32) is a DEVICE array here; workspace: qbm_kcenter_fused_workspace_bytes() bytes.  QBM_ERR_ARG where the shape does not
+ * fit (N * D beyond what 256 LDS slices hold, N > 65536, fewer than 256 compute units): call qbm_kcenter_greedy then.  Word 9
+ * of the workspace (uint32) is a status: non-zero after the launch = its workgroups were not all resident or an XCD held more
+ * than 64 of them, the outputs are invalid and the caller repeats the selection with qbm_kcenter_greedy.  Same contract, same
+ * picks as qbm_kcenter_greedy. */
+QBM_API long qbm_kcenter_fused_workspace_bytes(void);
+QBM_API int qbm_kcenter_greedy_fused(const float* emb, int N, int D, const int32_t* seeds_dev, int n_seeds, int n_picks,
+                                     int32_t* picks, uint8_t* selected, void* workspace, void* stream);
+
 /* ---- Disc_QBM: QUBO sampler ------------------------------------------------------------------ */
 
 /* HIP replacement of the annealer behind Disc_QBM.get_samples / get_samples_batch
@@ -356,6 +368,17 @@ QBM_API int qbm_qubo_gibbs_ex(const float* lin, const float* J, int B, int R, in
 QBM_API int qbm_qubo_gibbs_dev(const float* lin, const float* J, int B, int R, int n, int sweeps, const float* beta_dev,
                                float beta0, float beta1, uint64_t seed, uint64_t offset, uint32_t chain0,
                                uint8_t* states, double* mean, void* stream);
+
+/* The sampler's operands from a QUBO matrix as the sample_Q protocol hands it over (src/qubo/sampler.py:26-33: one n x n
+ * matrix per call, minimise s^T Q s; upper-triangular by protocol, any square matrix accepted): Q [n,n] float64 (q_is_f64 != 0)
+ * or float32 on the device ->  lin[n] = fp32(diag Q),  J[n,n] = fp32(Q_offdiag + Q_offdiag^T) (symmetric, zero diagonal; the sum
+ * in Q's own precision),  rowabs[n] / rowmin[n] as qbm_qbm_couplings delivers them (inputs of qbm_qbm_beta_range),
+ * any_offdiag[1] = 1 if a quadratic term is non-zero (the reference short-circuits a QUBO without any: :13-17, :28-29). */
+QBM_API int qbm_qubo_from_Q(const void* Q, int q_is_f64, int n, float* lin, float* J, double* rowabs, double* rowmin,
+                            int* any_offdiag, void* stream);
+
+/* uint8 -> float32, n elements (sample_Q returns float32 samples) */
+QBM_API int qbm_u8_to_f32(const uint8_t* x, float* y, long n, void* stream);
 
 /* ---- Disc_QBM with device-resident parameters ---------------------------------------------------
  * theta = [W_vh (1+D)*H | W_vo D | b_h H | b_o 1] float64, the reference's arrays (src/model/faster_dqbm.py:196-216:

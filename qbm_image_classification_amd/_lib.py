@@ -86,11 +86,15 @@ SIGNATURES = {
     "qbm_data_gather": [_p, _i, _p, _i, _i, _p, _i, _p, _p, _p, _i, _p],
     "qbm_kcenter_workspace_bytes": [_i, _i],
     "qbm_kcenter_greedy": [_p, _i, _i, C.POINTER(C.c_int32), _i, _i, _p, _p, _p, _p],
+    "qbm_kcenter_fused_workspace_bytes": [],
+    "qbm_kcenter_greedy_fused": [_p, _i, _i, _p, _i, _i, _p, _p, _p, _p],
     "qbm_test_math": [_i, _p, _p, _i, _p],
     "qbm_test_uniform": [_u64, _u64, _u32, _i, _i, _p, _p],
     "qbm_qubo_gibbs": [_p, _p, _i, _i, _i, _i, _f, _f, _u64, _u64, _p, _p, _p],
     "qbm_qubo_gibbs_ex": [_p, _p, _i, _i, _i, _i, _f, _f, _u64, _u64, _u32, _p, _p, _p],
     "qbm_qubo_gibbs_dev": [_p, _p, _i, _i, _i, _i, _p, _f, _f, _u64, _u64, _u32, _p, _p, _p],
+    "qbm_qubo_from_Q": [_p, _i, _i, _p, _p, _p, _p, _p, _p],
+    "qbm_u8_to_f32": [_p, _p, C.c_long, _p],
     "qbm_qbm_linear_fields_dev": [_p, _p, _p, _i, _i, _i, C.c_double, _p, _p],
     "qbm_qbm_couplings": [_p, _p, _i, _i, C.c_double, _p, _p, _p, _p],
     "qbm_qbm_beta_range": [_p, _p, _p, _i, _i, _p, _p],

@@ -2,7 +2,8 @@
 
 `k_center_greedy` keeps the reference's signature and bookkeeping (`src/coreset.py:28-106`: `budget += 1`, the
 random first centre from `np.random.seed(random_seed)`, `index[select_mask]` as the result) and runs the picks on
-the GPU through `qbm_kcenter_greedy` (one launch per pick).  Only the Euclidean metric of the reference
+the GPU through `qbm_kcenter_greedy_fused` (all picks in one launch: 256 persistent workgroups with their rows in LDS) or,
+for shapes that kernel does not take, `qbm_kcenter_greedy` (one launch per pick).  Only the Euclidean metric of the reference
 (`euclidean_dist`, `:6-13`) is implemented; a custom `metric` callable is refused rather than silently ignored.
 `random_downsampling` (`:123-141`) is host-side numpy, as in the reference.  No CPU fallback for the picks."""
 from __future__ import annotations
@@ -24,16 +25,38 @@ def euclidean_dist(x, y):
     return torch.sqrt(torch.clamp(sq, min=1e-12))
 
 
-def kcenter_picks(emb, seeds, n_picks, device="cuda:0"):
-    """Device picks for given seed centres -> (picks int32 [n_picks], selected uint8 [N]) as device tensors."""
+def kcenter_picks(emb, seeds, n_picks, device="cuda:0", fused=None):
+    """Device picks for given seed centres -> (picks int32 [n_picks], selected uint8 [N]) as device tensors.
+    fused: True / False = the one-launch kernel (qbm_kcenter_greedy_fused) / one launch per pick; None = the one-launch kernel
+    where the shape fits it, and -- should that launch report that its workgroups were not all resident -- the selection is
+    repeated with one launch per pick (same contract, same picks)."""
     lib = _lib.load()
     if not torch.cuda.is_available():
         raise _lib.QbmHipError("no ROCm device visible: the HIP path cannot run (there is no CPU fallback)")
     dev = torch.device(device)
-    emb = torch.as_tensor(emb).to(dev, torch.float32)
+    emb = torch.as_tensor(emb).to(dev, torch.float32).contiguous()
     n, d = emb.shape
-    embT = emb.t().contiguous()
     seeds = np.ascontiguousarray(seeds, dtype=np.int32)
+    if fused is None or fused:
+        seeds_dev = torch.from_numpy(seeds).to(dev)
+        ws = torch.empty(lib.qbm_kcenter_fused_workspace_bytes(), dtype=torch.uint8, device=dev)
+        picks = torch.empty(max(n_picks, 1), dtype=torch.int32, device=dev)
+        selected = torch.empty(n, dtype=torch.uint8, device=dev)
+        rc = lib.qbm_kcenter_greedy_fused(ptr(emb), n, d, ptr(seeds_dev), len(seeds), n_picks, ptr(picks), ptr(selected), ptr(ws),
+                                          current_stream())
+        if rc == 0:
+            status = int(ws.view(torch.int32)[9].item())      # (synchronises: the caller reads the picks next anyway)
+            if status == 0:
+                return picks[:n_picks], selected
+            if fused:
+                raise _lib.QbmHipError(f"one-launch k-center kernel gave up (status {status}): its workgroups were not all resident")
+            import warnings
+
+            warnings.warn(f"one-launch k-center kernel gave up (status {status}); repeating the selection with one launch per pick",
+                          RuntimeWarning)
+        elif fused:
+            check(rc, "qbm_kcenter_greedy_fused")
+    embT = emb.t().contiguous()
     ws = torch.empty(lib.qbm_kcenter_workspace_bytes(n, len(seeds)), dtype=torch.uint8, device=dev)
     picks = torch.empty(max(n_picks, 1), dtype=torch.int32, device=dev)
     selected = torch.empty(n, dtype=torch.uint8, device=dev)

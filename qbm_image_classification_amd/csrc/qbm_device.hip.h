@@ -143,22 +143,33 @@ __device__ __forceinline__ float wave_butterfly_sum(float p)
     return p;
 }
 
-// [Q] the NQ chains a contraction of length K is cut into: WHOLE 16-k staging pieces, dealt as evenly as they go -- with
-// P = ceil(K / 16) pieces every chain takes P / NQ of them and the LAST P % NQ chains one more (K = 784, NQ = 8: 49 pieces =
-// 6,6,6,6,6,6,6,7; round 3 cut K into NQ chains of roundup16(ceil(K / NQ)) = 7,7,7,7,7,7,7,0 pieces: one wavefront of eight
-// idle and the critical SIMD a piece longer).  Chain q covers k in [k0, k1).  NQ = 4 ("quarters": the gradient, contracted over
-// the batch) or 8 (the conditionals).  Restated in oracle/qbm_oracle.c::chain_range.
+// [Q] the NQ chains a contraction of length K is cut into: contiguous chains of Kq = roundup16(ceil(K / NQ)) terms -- a whole
+// number of 16-k staging pieces; the last ones may be short or empty.  Chain q covers k in [k0, k1).  NQ = 4 ("quarters": the
+// gradient, contracted over the batch) or 8 (the conditionals).  Restated in oracle/qbm_oracle.c::chain_range.
+// Round 4 measured the alternative the stamps suggested -- the pieces dealt as evenly as they go (K = 784, NQ = 8: 49 pieces =
+// 6,6,6,6,6,6,6,7 instead of 7,7,7,7,7,7,7,0: no idle wavefront, the critical SIMD a piece shorter) -- bit-exact against an
+// oracle restated in lock-step, goldens within tolerance, and 0.05 us per k_hidden launch SLOWER in three alternating A/B runs
+// of one session (5.91-5.94 against 5.86-5.91 us; k_visible, K = 512, is the same under both rules): the MFMA loop gets shorter
+// (2.6 k instead of 3.0 k cycles per wavefront) but eight wavefronts asking for their first quad at once land it later (2.8 k
+// instead of 2.5 k).  Kept as a diagnostic build (-DQBM_DIAG_BALANCED_CHAINS: NOT the contract the oracle restates) with its
+// numbers (profiles/r04_ab_strips_chains.jsonl).
 __host__ __device__ __forceinline__ void chain_range(int K, int nq, int q, int& k0, int& k1)
 {
+#ifdef QBM_DIAG_BALANCED_CHAINS
     const int P = (K + 15) >> 4, base = P / nq, rem = P - base * nq;
     const int extra = q - (nq - rem);                  // chains in front of q that hold one piece more (if positive)
     const int p0 = q * base + (extra > 0 ? extra : 0);
     const int np = base + (q >= nq - rem ? 1 : 0);
     k0 = 16 * p0 < K ? 16 * p0 : K;
     k1 = 16 * (p0 + np) < K ? 16 * (p0 + np) : K;
+#else
+    const int Kq = (((K + nq - 1) / nq) + 15) / 16 * 16;
+    k0 = q * Kq < K ? q * Kq : K;
+    k1 = (q + 1) * Kq < K ? (q + 1) * Kq : K;
+#endif
 }
 // length of the longest chain (a whole number of pieces): what panels and LDS images are sized for
-__host__ __device__ __forceinline__ int chain_len(int K, int nq) { return ((((K + 15) >> 4) + nq - 1) / nq) * 16; }
+__host__ __device__ __forceinline__ int chain_len(int K, int nq) { return (((K + nq - 1) / nq) + 15) / 16 * 16; }
 __host__ __device__ __forceinline__ int quarter_len(int K) { return chain_len(K, 4); }
 
 }  // namespace qbm

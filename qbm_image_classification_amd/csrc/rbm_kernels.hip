@@ -48,14 +48,19 @@ constexpr int V_MT = QBM_V_MT, V_NT = 1;
 // round too: 64 x 16 strips for the two-phase form at 784 x 512 cost 9.6 instead of 8.5 us per launch (every data tile is
 // staged twice as often), B = 2048: 135 instead of 126 us per step.
 constexpr int G_MT = 4;
-// Round 4: 112 x 16 strips (MT = 7, NT = 1) for the two-phase form where they tile V exactly and fill more CUs than the 64 x 32
-// ones: 784 = 7 x 112, so 784 x 512 is 7 x 32 = 224 full workgroups -- the 64 x 32 strips cut 784 rows into 12 1/4: 13 x 16 = 208
-// workgroups on 256 CUs, the 13th row strip a quarter full (94 % useful MFMAs); per workgroup 7/8 of the MFMA work and 88 KB
-// instead of 96 KB staged.  The seven row tiles of a strip share one merged uint8 image (seven 16-byte slots per k: 112-byte
-// rows, conflict-free for ds_read_u8), filled by seven 1-KiB transfers per 64 k.
+// Round 4 built 112 x 16 strips (MT = 7, NT = 1) for the two-phase form where they tile V exactly and fill more CUs than the
+// 64 x 32 ones: 784 = 7 x 112, so 784 x 512 is 7 x 32 = 224 full workgroups -- the 64 x 32 strips cut 784 rows into 12 1/4:
+// 13 x 16 = 208 workgroups on 256 CUs, the 13th row strip a quarter full (94 % useful MFMAs); per workgroup 7/8 of the MFMA work
+// and 88 KB instead of 96 KB staged.  The seven row tiles of a strip share one merged uint8 image (seven 16-byte slots per k:
+// 112-byte rows, conflict-free for ds_read_u8), filled by seven 1-KiB transfers per 64 k.  Bit-identical (every GPU parity test)
+// -- and SLOWER: k_grad 8.68-8.74 us against 8.39-8.41 with the 64 x 32 strips in three alternating A/B runs of one session
+// (profiles/r04_ab_strips_chains.jsonl; CD-1 step 28.13-28.18 against 27.86-27.90 us).  A wavefront of the tall strip stages
+// 7 KB of data + 4 KB of probabilities behind 11 transfer instructions for 112 MFMAs, the wide one 4 + 8 KB behind 12 for 128:
+// what the launch waits for is the staging of a cold start, not the MFMAs or the 48 idle CUs.  Opt-in for diagnostic builds
+// (-DQBM_GRAD_112=1).
 constexpr int G_MT7 = 7;
-#ifndef QBM_GRAD_112   // diagnostic builds: 0 = never take the 112 x 16 strips (A/B timing)
-#define QBM_GRAD_112 1
+#ifndef QBM_GRAD_112
+#define QBM_GRAD_112 0
 #endif
 
 // class-count buckets for the kernels that keep one register (or one float4) per class

@@ -138,7 +138,13 @@ def auto_beta_range(lin: np.ndarray, J: np.ndarray):
 
 
 class HipGibbsSampler:
-    """Drop-in for src/qubo/sampler.py::LocalSASampler (same constructor keywords, same sample_Q)."""
+    """Drop-in for src/qubo/sampler.py::LocalSASampler (same constructor keywords, same sample_Q).
+
+    The protocol hands over ONE host matrix per call (src/train/pipeline.py:20, 35), so what a call costs besides the sweeps
+    is host work and PCIe.  Round 4: the matrix goes to the device AS IT IS through a pinned staging buffer the sampler keeps
+    (one memcpy, one asynchronous copy), and everything numpy did per call -- the diagonal, (off + off.T).astype(float32), the
+    annealing range -- happens there in two launches (qbm_qubo_from_Q, qbm_qbm_beta_range); the samples come back as float32
+    through a second pinned buffer.  One synchronisation per call."""
 
     def __init__(self, num_sweeps: int = 1000, seed: int | None = None, beta_range=None, device="cuda:0"):
         self.ops = HipQuboOps(device)
@@ -146,26 +152,57 @@ class HipGibbsSampler:
         self.seed = 0 if seed is None else int(seed)
         self.beta_range = None if beta_range is None else (float(beta_range[0]), float(beta_range[1]))
         self._calls = 0
+        self._bufs = {}     # (n, dtype, reads) -> staging and device buffers, kept from call to call
+
+    def _buffers(self, n, dtype, reads):
+        key = (n, dtype, reads)
+        b = self._bufs.get(key)
+        if b is None:
+            if len(self._bufs) >= 4:
+                self._bufs.pop(next(iter(self._bufs)))
+            dev = self.ops.device
+            f = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=dev)
+            b = self._bufs[key] = dict(
+                q_pin=torch.empty(n * n, dtype=dtype).pin_memory(), q_dev=f(n * n, dt=dtype), lin=f(1, n), J=f(n, n),
+                rowabs=f(n, dt=torch.float64), rowmin=f(n, dt=torch.float64), any_off=torch.zeros(1, dtype=torch.int32, device=dev),
+                beta=f(1, 2), states=torch.empty(1, reads, n, dtype=torch.uint8, device=dev), out=f(reads, n),
+                out_pin=torch.empty(reads, n, dtype=torch.float32).pin_memory(), flag_pin=torch.zeros(1, dtype=torch.int32).pin_memory())
+            if self.beta_range is not None:
+                b["beta"].copy_(torch.tensor([self.beta_range], dtype=torch.float32))
+            b["q_np"] = b["q_pin"].numpy().reshape(n, n)
+        return b
 
     def sample_Q(self, Q: np.ndarray, num_reads: int) -> np.ndarray:
         """Q: upper-triangular QUBO (minimise s^T Q s) -> float32 [num_reads, n] in {0,1}, column j = variable j
         (src/qubo/sampler.py:26-33)."""
-        Q = np.asarray(Q, dtype=np.float64)
+        Q = np.asarray(Q)
+        if Q.dtype != np.float32:
+            Q = np.asarray(Q, dtype=np.float64)
         if Q.ndim != 2 or Q.shape[0] != Q.shape[1]:
             raise ValueError("QUBO matrix must be square")
-        n = Q.shape[0]
-        lin = np.diag(Q).astype(np.float32)[None, :]
-        off = Q - np.diag(np.diag(Q))
-        if not off.any():
+        n, reads = Q.shape[0], int(num_reads)
+        f64 = Q.dtype == np.float64
+        b = self._buffers(n, torch.float64 if f64 else torch.float32, reads)
+        lib, st = self.ops.lib, current_stream()
+        np.copyto(b["q_np"], Q)                                           # the call's one pass over the matrix on the host
+        b["q_dev"].copy_(b["q_pin"], non_blocking=True)
+        check(lib.qbm_qubo_from_Q(ptr(b["q_dev"]), int(f64), n, ptr(b["lin"]), ptr(b["J"]), ptr(b["rowabs"]), ptr(b["rowmin"]),
+                                  ptr(b["any_off"]), st), "qbm_qubo_from_Q")
+        if self.beta_range is None:   # hot / cold from the QUBO's coefficients, on the device (auto_beta_range is the host statement)
+            check(lib.qbm_qbm_beta_range(ptr(b["lin"]), ptr(b["rowabs"]), ptr(b["rowmin"]), 1, n, ptr(b["beta"]), st), "qbm_qbm_beta_range")
+        check(lib.qbm_qubo_gibbs_dev(ptr(b["lin"]), ptr(b["J"]), 1, reads, n, self.num_sweeps, ptr(b["beta"]), 1.0, 1.0, self.seed,
+                                     self._calls << 20, 0, ptr(b["states"]), None, st), "qbm_qubo_gibbs_dev")
+        check(lib.qbm_u8_to_f32(ptr(b["states"]), ptr(b["out"]), reads * n, st), "qbm_u8_to_f32")
+        b["out_pin"].copy_(b["out"], non_blocking=True)
+        b["flag_pin"].copy_(b["any_off"], non_blocking=True)
+        torch.cuda.current_stream().synchronize()                         # the call's one synchronisation
+        self._calls += 1
+        if int(b["flag_pin"][0]) == 0:
             # the reference short-circuits a QUBO without quadratic terms (src/qubo/sampler.py:13-17, 28-29):
             # s_i = 1 if h_i < 0, 0 if h_i > 0, a coin (one draw per variable, shared by all reads) if h_i == 0
+            self._calls -= 1          # (no draws were consumed by the protocol's answer)
             h = np.diag(Q)
             coin = np.random.default_rng(self.seed).integers(0, 2, size=n)
             sol = np.where(h < 0, 1, np.where(h > 0, 0, coin)).astype(np.float32)
-            return np.tile(sol, (int(num_reads), 1))
-        J = (off + off.T).astype(np.float32)
-        b0, b1 = self.beta_range if self.beta_range is not None else auto_beta_range(lin, J)
-        states, _ = self.ops.gibbs(torch.from_numpy(lin), torch.from_numpy(J), int(num_reads), self.num_sweeps,
-                                   b0, b1, self.seed, self._calls << 20, want_mean=False)
-        self._calls += 1
-        return states[0].to(torch.float32).cpu().numpy()
+            return np.tile(sol, (reads, 1))
+        return b["out_pin"].numpy().copy()

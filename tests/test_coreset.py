@@ -57,11 +57,17 @@ def test_hip_kcenter_matches_oracle_and_reference(oracle):
     # pick ORDER and mask against the oracle on shapes the goldens do not cover (more rows than one launch's
     # workgroups x threads in one stride, wide embeddings, duplicate points = exact distance ties)
     rs = np.random.RandomState(4)
-    for n, d, seeds, picks in ((5000, 256, [17], 300), (300, 7, [0, 299, 5], 120), (263, 1, [2], 50)):
+    for n, d, seeds, picks in ((5000, 256, [17], 300), (300, 7, [0, 299, 5], 120), (263, 1, [2], 50), (1000, 8, [0, 999, 5], 400),
+                               (257, 4, [256], 257), (90, 64, [3], 40)):
         emb = rs.standard_normal((n, d)).astype(np.float32)
         emb[n // 2:n // 2 + 20] = emb[:20]                      # duplicates
         want_p, want_s = oracle.kcenter_picks(emb, seeds, picks)
-        got_p, got_s = coreset.kcenter_picks(emb, seeds, picks)
+        # both device paths: all picks in ONE launch (persistent workgroups, rows in LDS, one granule per pick: shapes with
+        # D a multiple of 4) and one launch per pick
+        for fused in ((True, False) if d % 4 == 0 else (False,)):
+            got_p, got_s = coreset.kcenter_picks(emb, seeds, picks, fused=fused)
+            assert np.array_equal(got_p.cpu().numpy(), want_p) and np.array_equal(got_s.cpu().numpy(), want_s), (n, d, fused)
+        got_p, got_s = coreset.kcenter_picks(emb, seeds, picks)    # the default: whichever takes the shape
         assert np.array_equal(got_p.cpu().numpy(), want_p) and np.array_equal(got_s.cpu().numpy(), want_s)
 
 
@@ -73,7 +79,9 @@ def test_hip_kcenter_full_size_properties():
 
     rs = np.random.RandomState(0)
     emb = (rs.random_sample((12665, 256)) < 0.3).astype(np.float32) * rs.random_sample((12665, 256)).astype(np.float32)
-    picks, sel = coreset.kcenter_picks(emb, [123], 501)
+    picks, sel = coreset.kcenter_picks(emb, [123], 501, fused=True)      # 256 persistent workgroups, 50 rows each in LDS
+    picks1, sel1 = coreset.kcenter_picks(emb, [123], 501, fused=False)   # one launch per pick
+    assert torch.equal(picks, picks1) and torch.equal(sel, sel1)
     p = picks.cpu().numpy()
     assert p[0] == 123 and len(set(p.tolist())) == 501 and int(sel.sum().item()) == 501
     e = torch.from_numpy(emb).cuda()

@@ -504,8 +504,11 @@ def test_qubo_gibbs_bitwise(oracle):
                                       (8, 16, 257, 3, 0.2, 2.0), (4, 32, 65, 5, 1.0, 1.0), (2, 40, 276, 2, 0.5, 1.5),
                                       (70, 1, 7, 4, 1.0, 1.0), (150, 40, 33, 2, 0.3, 3.0), (2, 40, 277, 2, 0.5, 1.5),
                                       (1, 70, 700, 2, 0.7, 1.3),
-                                      # more chains than wavefronts: every wavefront walks two chains in lockstep (+ one alone)
-                                      (45, 100, 130, 3, 0.3, 2.0), (90, 100, 65, 2, 0.5, 1.5), (50, 100, 257, 2, 0.2, 2.5)]:
+                                      # more chains than wavefronts: every wavefront walks several chains, one after the other
+                                      (45, 100, 130, 3, 0.3, 2.0), (90, 100, 65, 2, 0.5, 1.5), (50, 100, 257, 2, 0.2, 2.5),
+                                      # n = 64 k + 1: k whole tiles + the last spin as a wave-uniform scalar (round 4), both readers
+                                      (3, 30, 129, 4, 0.3, 2.0), (2, 10, 193, 3, 1.0, 1.0), (3, 40, 193, 3, 0.2, 3.0), (1, 9, 321, 2, 0.5, 1.5),
+                                      (2, 5, 385, 2, 0.5, 1.5)]:
         lin = rs.standard_normal((B, n)).astype(np.float32)
         Ju = np.triu(rs.standard_normal((n, n)).astype(np.float32) * 0.3, 1)
         J = (Ju + Ju.T).astype(np.float32)

@@ -48,8 +48,7 @@ def test_det_math_accuracy(oracle):
 
 @pytest.mark.parametrize("nq,perm", [(4, False), (8, True), (8, False)])
 def test_qgemm_is_split_fma_chain(oracle, nq, perm):
-    """[Q]: nq contiguous chains of whole 16-term pieces dealt as evenly as they go -- P = ceil(K/16) pieces, P // nq each, the
-    LAST P % nq chains one more (K = 784, nq = 8: 6,6,6,6,6,6,6,7) --, each an fmaf chain, summed in chain order (8 chains: the
+    """[Q]: nq contiguous chains of roundup16(ceil(K/nq)) terms, each an fmaf chain, summed in chain order (8 chains: the
     conditionals; 4: the gradient blocks).  [Q']: the conditionals visit every aligned 16-term piece in the order
     0,4,8,12, 1,5,9,13, 2,6,10,14, 3,7,11,15 (terms beyond K skipped); the gradient in ascending order."""
     order = [4 * (j & 3) + (j >> 2) for j in range(16)] if perm else list(range(16))
@@ -58,19 +57,15 @@ def test_qgemm_is_split_fma_chain(oracle, nq, perm):
         A = rs.standard_normal((M, K)).astype(np.float32)
         B = rs.standard_normal((K, N)).astype(np.float32)
         got = oracle.qgemm(A, B, nq, perm)
-        P = (K + 15) // 16
-        npieces = [P // nq + (1 if q >= nq - P % nq else 0) for q in range(nq)]
-        first = [16 * sum(npieces[:q]) for q in range(nq)]
-        if K == 784 and nq == 8:
-            assert npieces == [6, 6, 6, 6, 6, 6, 6, 7]
+        Kq = ((K + nq - 1) // nq + 15) // 16 * 16
         want = np.zeros((M, N), np.float32)
         for m in range(M):
             for n in range(N):
                 parts = []
                 for q in range(nq):
                     acc = np.float32(0)
-                    k1 = min(K, first[q] + 16 * npieces[q])
-                    for k in (p0 + j for p0 in range(first[q], k1, 16) for j in order if p0 + j < k1):
+                    k1 = min(K, (q + 1) * Kq)
+                    for k in (p0 + j for p0 in range(q * Kq, k1, 16) for j in order if p0 + j < k1):
                         # exact fma in float64: a*b is exact (48 bits), the sum is rounded once to
                         # 53 bits and again to 24 -- double rounding can differ only on ties
                         acc = np.float32(np.float64(A[m, k]) * np.float64(B[k, n]) + np.float64(acc))
