@@ -1,7 +1,7 @@
 # Evidence for profiles/: rocprofv3 kernel stats (bench + every other hot-path kernel), PMC passes (HBM traffic; MFMA busy),
 # the bench line, the in-kernel stamps.  Output under gpurun_out/profiles/ (copy into profiles/ afterwards).
-#   ROUND=r03 bash tools/gpu_profiles.sh
-R=${ROUND:-r03}
+#   ROUND=r04 bash tools/gpu_profiles.sh
+R=${ROUND:-r04}
 ROOT=$GRAFT_REPO_ROOT; [ -z "$ROOT" ] && ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles; mkdir -p $OUT; P=$ROOT/gpurun_out/progress.log; : > $P
 cd /tmp && export TMPDIR=/tmp
