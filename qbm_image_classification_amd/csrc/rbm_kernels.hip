@@ -1315,7 +1315,8 @@ __device__ __forceinline__ void grad_w_strip_par(const GradArgs& a, int m0, int 
         if (mine_to_finish) w_old = grad_w_tile<SO>(a, m0, n0, my_op);
     };
     QBM_STAMP(11);
-    const SO mine = strip_mma<MT, NT, FAST, FAST>(Dm, Pm, m0, n0, a.B, lds, a.KP, pre0, NoPre{}, first ? 0 : 5);
+    // (piece waits: a chain of a minibatch of 256 rows is ONE quad -- strip_mma's PW)
+    const SO mine = strip_mma<MT, NT, FAST, FAST, 4, 4, false, 0, 0, kWhole, 0, true>(Dm, Pm, m0, n0, a.B, lds, a.KP, pre0, NoPre{}, first ? 0 : 5);
     float4* x = reinterpret_cast<float4*>(lds_all);   // every thread has left strip_mma: the staging regions are free
     if constexpr (SO::NP == 2) {
         // group 0 finishes output 0 and needs phase 1's output 0; group 1 finishes output 1 and needs phase 0's output 1
@@ -1435,9 +1436,9 @@ __global__ __launch_bounds__(PAR ? 512 : 256) void k_grad(GradArgs a)
             for (int op = 0; op < SO::NP; ++op) w_old[op] = grad_w_tile<SO>(a, m0, n0, op);
         };
         QBM_STAMP(11);
-        const SO o0 = strip_mma<MT, NT, FAST, FAST>(D0, P0, m0, n0, a.B, lds, a.KP, pre0);
+        const SO o0 = strip_mma<MT, NT, FAST, FAST, 4, 4, false, 0, 0, kWhole, 0, true>(D0, P0, m0, n0, a.B, lds, a.KP, pre0);
         SO o1;   // ONE (the discriminative step: gW = x^T.(pos - neg)): zeros, g = o0 - 0 = o0
-        if constexpr (!ONE) o1 = strip_mma<MT, NT, FAST, FAST>(D1, P1, m0, n0, a.B, lds, a.KP, NoPre{}, NoPre{}, 5);
+        if constexpr (!ONE) o1 = strip_mma<MT, NT, FAST, FAST, 4, 4, false, 0, 0, kWhole, 0, true>(D1, P1, m0, n0, a.B, lds, a.KP, NoPre{}, NoPre{}, 5);
         else
 #pragma unroll
             for (int op = 0; op < SO::NP; ++op) o1.sum[op] = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -430,8 +430,15 @@ __device__ __forceinline__ int chain_transfers_b(int K, int KP)
     const int klen = max(0, min(k1 - k0, KP));
     return NT * ((klen + 15) >> 4);
 }
+// PW ("piece waits"; the gradient's single-quad chains: a wavefront's whole chain is ONE quad of 64 k, so nothing of its
+// staging can hide under its own MFMAs): the quad's transfers are requested piece by piece (the merged uint8 image's transfer
+// i IS piece i of all row tiles) and every piece is awaited by itself, so that the MFMAs of piece p run while pieces p + 2 ..
+// are still on their way (the fragment reads of piece p + 1 stand in front of the MFMAs of piece p).
+#ifndef QBM_PIECE_WAIT   // diagnostic builds: 0 = one wait for the whole quad (A/B timing)
+#define QBM_PIECE_WAIT 1
+#endif
 template <int MT, int NT, bool FAST_A, bool FAST_B, int CPT = 4, int NQ = 4, bool KPERM = false, int AUX_A = 0, int AUX_B = 0,
-          int PHASE = kWhole, int STAG = 0, class AView, class BView, class Pre0 = NoPre, class Pre = NoPre, class Post = NoPre>
+          int PHASE = kWhole, int STAG = 0, bool PW = false, class AView, class BView, class Pre0 = NoPre, class Pre = NoPre, class Post = NoPre>
 __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView& A, const BView& Bv, int m0, int n0, int K,
                                                                     char* __restrict__ lds, int KP, Pre0&& pre0 = NoPre{},
                                                                     Pre&& pre = NoPre{}, int stamp0 = 0,
@@ -583,8 +590,9 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
     };
     // the NP pieces of quad `qd`, straight-line (no branch inside: a merge point would cost register copies, and
     // copies are VALU work the MFMAs pay for)
-    auto run_quad_n = [&](auto NPC, int qd) {
+    auto run_quad_n = [&](auto NPC, int qd, auto PWC) {
         constexpr int NP = decltype(NPC)::value;
+        constexpr bool kPw = decltype(PWC)::value;   // piece p of a 4-piece quad requested piece by piece: (3 - p) (1 + NT) transfers younger than it
         using std::integral_constant;
         uint32_t adA[MT], adB[NT];
 #pragma unroll
@@ -605,6 +613,7 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
         auto stage = [&](auto NXT, Frag& fn, Frag& fc) {
             constexpr int nxt = decltype(NXT)::value;
             if constexpr (nxt < NP) {
+                if constexpr (kPw) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((3 - nxt) * (1 + NT)) : "memory");
                 reads1(NXT, fn);
                 asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(kChunk1) : "memory");   // everything older than chunk 1 has landed
                 tie(fc);
@@ -616,6 +625,7 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
             mma(fc);
         };
         Frag f0, f1;
+        if constexpr (kPw) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (1 + NT)) : "memory");
         reads1(integral_constant<int, 0>{}, f0);
         reads2(integral_constant<int, 0>{}, f0);
         stage(integral_constant<int, 1>{}, f1, f0);
@@ -625,14 +635,14 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
     };
     auto run_quad = [&](int qd, int np) {   // np = pieces in the quad, 1..4 (wave-uniform)
         using std::integral_constant;
-        if (np >= 4) run_quad_n(integral_constant<int, 4>{}, qd);
-        else if (np == 3) run_quad_n(integral_constant<int, 3>{}, qd);
-        else if (np == 2) run_quad_n(integral_constant<int, 2>{}, qd);
-        else if (np == 1) run_quad_n(integral_constant<int, 1>{}, qd);
+        if (np >= 4) run_quad_n(integral_constant<int, 4>{}, qd, std::false_type{});
+        else if (np == 3) run_quad_n(integral_constant<int, 3>{}, qd, std::false_type{});
+        else if (np == 2) run_quad_n(integral_constant<int, 2>{}, qd, std::false_type{});
+        else if (np == 1) run_quad_n(integral_constant<int, 1>{}, qd, std::false_type{});
     };
     auto run = [&](int p0, int p1) {   // whole quads from p0 (a multiple of 4)
         int pc = p0;
-        for (; pc + 4 <= p1; pc += 4) run_quad_n(std::integral_constant<int, 4>{}, pc >> 2);
+        for (; pc + 4 <= p1; pc += 4) run_quad_n(std::integral_constant<int, 4>{}, pc >> 2, std::false_type{});
         if (pc < p1) run_quad(pc >> 2, p1 - pc);
     };
 
@@ -660,6 +670,19 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
         };
         auto quad_pieces = [&](int qd) { return min(4, pieces - 4 * qd); };
         auto quad_dmas = [&](int qd) { return qd < quads ? (A8 ? MT : MT * quad_pieces(qd)) + nt_dma * quad_pieces(qd) : 0; };
+        // PW: a chain that is exactly one full quad, requested piece by piece
+        constexpr bool kPwOk = PW && QBM_PIECE_WAIT && A8 && !A_K4 && MT == 4 && PHASE == kWhole;
+        auto issue_quad_pw = [&]() {
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) {
+                blds16<AUX_A>(ra, la[pc].voff, imgA + pc * 1024);            // transfer pc of the merged image = piece pc of all 4 tiles
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    blds16<AUX_B>(rb, lb[t].voff, imgB + t * b_tile + pc * 1024);
+                    lb[t].voff += lb[t].step;
+                }
+            }
+        };
         auto issue_quad = [&](int qd, bool do_a = true, bool do_b = true) {
             const int np = quad_pieces(qd);
             if constexpr (A8) {
@@ -717,7 +740,10 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
         // (stag_on: the caller's run-time say)
         if constexpr (STAG > 0 && NQ == 8)
             if (q >= 4 && stag_on) __builtin_amdgcn_s_sleep(STAG);
-        if (qbm_diag != 4 && quads > 0) issue_quad(0);
+        bool pw = false;
+        if constexpr (kPwOk) pw = quads == 1 && pieces == 4 && !b_resident && kend - kq0 <= KP && qbm_diag == 0;
+        if (pw) issue_quad_pw();
+        else if (qbm_diag != 4 && quads > 0) issue_quad(0);
         pre0();
         if (ahead >= 2 && qbm_diag != 4 && quads > 1) issue_quad(1);
         QBM_STAMP(stamp0 + 1);
@@ -732,13 +758,20 @@ __device__ __forceinline__ StripOut<MT, NT, CPT, 64 * NQ> strip_mma(const AView&
             // run in one loop body (one code path: the accumulators stay in place).
             const int full = pieces >> 2;
             int qd = 0;
+            if constexpr (kPwOk)
+                if (pw) {   // (the hooks' own vector-memory operations -- the W tile of the fused update -- are younger than every
+                            //  piece and are awaited by their consumer: the counted waits below leave them in flight... see below)
+                    QBM_STAMP(stamp0 + 2);
+                    run_quad_n(std::integral_constant<int, 4>{}, 0, std::true_type{});
+                    qd = quads;
+                }
             for (; qd < full; ++qd) {
                 if (qbm_diag != 4) {
                     if (qd + ahead < quads) issue_quad(qd + ahead);
                     vm_wait(qbm_diag == 1 ? 0 : quad_dmas(qd + 1) + (ahead >= 2 ? quad_dmas(qd + 2) : 0));
                 }
                 if (qd == 0) QBM_STAMP(stamp0 + 2);
-                if (qbm_diag != 3) run_quad_n(std::integral_constant<int, 4>{}, qd);
+                if (qbm_diag != 3) run_quad_n(std::integral_constant<int, 4>{}, qd, std::false_type{});
             }
             if (qd < quads) {   // tail quad: 1..3 pieces, nothing is in flight behind it
                 if (qbm_diag != 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
