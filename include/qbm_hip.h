@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define QBM_ABI_VERSION 14
+#define QBM_ABI_VERSION 15
 #define QBM_MAX_CLASSES 15 /* class rows + the bias row share one 16-row gradient tile */
 #define QBM_MAX_QUBO_VARS 1024
 
@@ -376,6 +376,24 @@ QBM_API int qbm_qubo_gibbs_dev(const float* lin, const float* J, int B, int R, i
  * any_offdiag[1] = 1 if a quadratic term is non-zero (the reference short-circuits a QUBO without any: :13-17, :28-29). */
 QBM_API int qbm_qubo_from_Q(const void* Q, int q_is_f64, int n, float* lin, float* J, double* rowabs, double* rowmin,
                             int* any_offdiag, void* stream);
+
+/* ---- sparse couplings: the rows of J as CSR entries in LDS (round 4) --------------------------------
+ * For QUBOs whose triangle does not fit a CU's LDS (n > 276) but whose NON-ZERO couplings do: the conv-QBM QUBOs behind
+ * sample_Q (src/qubo/sampler.py:26-33; n = 717 with 5762 non-zero entries of 514 089).  Same chain, same draws, same
+ * states bit for bit as qbm_qubo_gibbs_dev on the same (lin, J): only where a flip finds its row differs.
+ *   cap = qbm_qubo_csr_max_entries(n, B * R)      entries the LDS holds beside the chains' fields (0: bad arguments)
+ *   ws  = qbm_qubo_csr_workspace_bytes(n, cap)    device bytes, 8-byte aligned
+ *   qbm_qubo_csr_build(J, n, cap, ws)             J [n,n] fp32 symmetric, diagonal ignored -> CSR (ascending columns)
+ *   qbm_qubo_gibbs_csr(lin, ws, cap, ...)         the sampler; arguments as qbm_qubo_gibbs_dev
+ * The first int32 of the workspace is a STATUS word the build writes: 0, or 1 if J holds more than cap non-zero
+ * couplings.  With status 1 the sampler launch does nothing (states, mean untouched): the caller reads the word at its next
+ * synchronisation and calls qbm_qubo_gibbs_dev instead.  The second int32 is the number of non-zero couplings found. */
+QBM_API long qbm_qubo_csr_max_entries(int n, int chains);
+QBM_API size_t qbm_qubo_csr_workspace_bytes(int n, long cap);
+QBM_API int qbm_qubo_csr_build(const float* J, int n, long cap, void* workspace, void* stream);
+QBM_API int qbm_qubo_gibbs_csr(const float* lin, const void* workspace, long cap, int B, int R, int n, int sweeps,
+                               const float* beta_dev, float beta0, float beta1, uint64_t seed, uint64_t offset, uint32_t chain0,
+                               uint8_t* states, double* mean, void* stream);
 
 /* uint8 -> float32, n elements (sample_Q returns float32 samples) */
 QBM_API int qbm_u8_to_f32(const uint8_t* x, float* y, long n, void* stream);

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # developer's switch for A/B timing inside one GPU session, never a fallback -- the file must exist and pass the ABI check
 SO = os.environ.get("QBM_HIP_LIB") or os.path.join(HERE, "libqbm_hip.so")
 
-QBM_ABI_VERSION = 14
+QBM_ABI_VERSION = 15
 QBM_MAX_CLASSES = 15
 QBM_F32, QBM_U8 = 0, 1
 
@@ -95,6 +95,10 @@ SIGNATURES = {
     "qbm_qubo_gibbs_dev": [_p, _p, _i, _i, _i, _i, _p, _f, _f, _u64, _u64, _u32, _p, _p, _p],
     "qbm_qubo_from_Q": [_p, _i, _i, _p, _p, _p, _p, _p, _p],
     "qbm_u8_to_f32": [_p, _p, C.c_long, _p],
+    "qbm_qubo_csr_max_entries": [_i, _i],
+    "qbm_qubo_csr_workspace_bytes": [_i, C.c_long],
+    "qbm_qubo_csr_build": [_p, _i, C.c_long, _p, _p],
+    "qbm_qubo_gibbs_csr": [_p, _p, C.c_long, _i, _i, _i, _i, _p, _f, _f, _u64, _u64, _u32, _p, _p, _p],
     "qbm_qbm_linear_fields_dev": [_p, _p, _p, _i, _i, _i, C.c_double, _p, _p],
     "qbm_qbm_couplings": [_p, _p, _i, _i, C.c_double, _p, _p, _p, _p],
     "qbm_qbm_beta_range": [_p, _p, _p, _i, _i, _p, _p],
@@ -124,7 +128,7 @@ def load() -> C.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name == "qbm_last_error" else C.c_long if name.endswith("_bytes") else C.c_int
+        fn.restype = C.c_char_p if name == "qbm_last_error" else C.c_long if name.endswith(("_bytes", "_max_entries")) else C.c_int
     if lib.qbm_abi_version() != QBM_ABI_VERSION:
         raise QbmHipError(f"ABI mismatch: library {lib.qbm_abi_version()} vs binding {QBM_ABI_VERSION}")
     _lib = lib

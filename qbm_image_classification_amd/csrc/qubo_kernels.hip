@@ -319,6 +319,202 @@ __global__ __launch_bounds__(64 * kGibbsLdsWaves) void k_qubo_gibbs_lds(const fl
         gibbs_chain<NF, JTri<NF>, XS>(lin, jr, J + (long)(n - 1) * n, ch, R, n, sweeps, beta0, beta1, beta_dev, seed, offset, chain0, states, lane);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sparse couplings (round 4): a QUBO whose triangle does not fit the LDS (n > 276) but whose NON-ZERO couplings do -- the
+// conv-QBM QUBOs of src/qubo/sampler.py's sample_Q protocol: n = 717, 5762 non-zero entries of 514 089, every row of J a
+// 2.9 KB read from L2 of which 8 words matter.  The rows live in LDS as CSR entries {byte offset of the column, value}; the
+// chain's FIELDS live in LDS as well (n floats per wavefront), because a flip now touches the fields of the row's few
+// neighbours, whichever lanes would hold them: one ds_read_b64 of the row's entries (lane e takes entry e) and one
+// ds_add_f32 into F[column] -- no return value, different addresses within a row, and the LDS executes a wavefront's
+// operations in order, so the re-test of the tile (a ds_read_b32 of its 64 fields) sees them.  A flip costs two LDS round
+// trips instead of an L2 one (~800 cycles) plus NF fused multiply-adds.
+// Same visit order, same draws, same thresholds as gibbs_chain; a field receives sg * J_pk for the flips p in sweep order:
+// fl(F +- J) is what fmaf(+-1, J, F) rounds to, and the entries the sparse row leaves out are the oracle's fmaf(+-1, 0, F) = F
+// (a field of -0 stays -0 instead of becoming +0: equal in every comparison made of it).  Bit-identical states.
+// (ds_add_f32 rounds to nearest even and keeps denormals under this build's FP mode: tests/test_gpu_parity.py holds a QUBO of
+// denormal couplings against the oracle.)
+// ---------------------------------------------------------------------------------------------
+struct CsrHead {        // front of the CSR workspace (device memory): include/qbm_hip.h, qbm_qubo_csr_build
+    int status;         // 1: more non-zero couplings than the workspace (or the LDS) holds -- the sampler launch does nothing
+    int nnz;
+    int cap;
+    int pad;
+};
+
+// non-zero entries per row: one wavefront per row
+__global__ __launch_bounds__(64) void k_csr_count(const float* __restrict__ J, int n, int* __restrict__ cnt)
+{
+    const int r = blockIdx.x, lane = threadIdx.x;
+    int c = 0;
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        const int k = k0 + lane;
+        const bool nz = k < n && k != r && J[(long)r * n + k] != 0.0f;
+        c += __builtin_popcountll(__ballot(nz));
+    }
+    if (lane == 0) cnt[r] = c;
+}
+
+// rowptr and the entries in ascending column order: one wavefront per row (its start = the sum of the counts in front of it)
+__global__ __launch_bounds__(64) void k_csr_fill(const float* __restrict__ J, int n, const int* __restrict__ cnt,
+                                                 CsrHead* __restrict__ head, int* __restrict__ rowptr, uint2* __restrict__ ent, int cap)
+{
+    const int r = blockIdx.x, lane = threadIdx.x;
+    int s = 0;
+    for (int i = lane; i < r; i += 64) s += cnt[i];
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    int pos = s;
+    if (lane == 0) rowptr[r] = s;
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        const int k = k0 + lane;
+        const float v = (k < n && k != r) ? J[(long)r * n + k] : 0.0f;
+        const unsigned long long m = __ballot(v != 0.0f);
+        const int e = pos + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (v != 0.0f && e < cap) ent[e] = make_uint2((unsigned)(4 * k), __float_as_uint(v));
+        pos += __builtin_popcountll(m);
+    }
+    if (r == n - 1 && lane == 0) {
+        rowptr[n] = pos;
+        head->nnz = pos;
+        head->cap = cap;
+        head->status = pos > cap ? 1 : 0;
+    }
+}
+
+constexpr int kCsrMaxWaves = 8;
+constexpr int kCsrLdsBytes = 160 * 1024;
+
+template <int NF>
+__global__ __launch_bounds__(64 * kCsrMaxWaves) void k_qubo_gibbs_csr(const float* __restrict__ lin, const CsrHead* __restrict__ head,
+                                                                       const int* __restrict__ rowptr, const uint2* __restrict__ ent,
+                                                                       int ent_cap /* entries the LDS holds */, int nchains, int R, int n,
+                                                                       int sweeps, float beta0, float beta1,
+                                                                       const float* __restrict__ beta_dev, uint64_t seed,
+                                                                       uint64_t offset, uint32_t chain0, uint8_t* __restrict__ states)
+{
+    extern __shared__ uint2 s_ent[];
+    if (head->status != 0) return;                       // (uniform: every workgroup reads the same word)
+    const int nnz = rowptr[n];
+    if (nnz > ent_cap) return;                           // (the host sized the LDS for head->cap: cannot happen with status == 0)
+    for (int i = threadIdx.x; i < nnz; i += blockDim.x) s_ent[i] = ent[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int waves = (int)blockDim.x >> 6;
+    float* Fw = reinterpret_cast<float*>(s_ent + ent_cap) + w * 64 * NF;   // this wavefront's fields
+    // lane l: where the entries of the row of spin 64 t + l lie (byte offset in s_ent, 24 bits) and how many (8 bits, 255 = more)
+    unsigned rinfo[NF];
+#pragma unroll
+    for (int t = 0; t < NF; ++t) {
+        const int i = 64 * t + lane;
+        const int r0 = i < n ? rowptr[i] : 0, r1 = i < n ? rowptr[i + 1] : 0;
+        rinfo[t] = (unsigned)(8 * r0) | ((unsigned)min(r1 - r0, 255) << 24);
+    }
+    // sg * J[p, :] into the fields: lane e takes entry rs + e (rows of more than 64 neighbours go round again)
+    auto add_row = [&](int rs, int re, unsigned sgbit) {
+        for (int e0 = rs; e0 < re; e0 += 64) {
+            const int e = e0 + lane;
+            if (e < re) {
+                const uint2 en = s_ent[e];
+                float* f = reinterpret_cast<float*>(reinterpret_cast<char*>(Fw) + en.x);
+                __hip_atomic_fetch_add(f, __uint_as_float(en.y ^ sgbit), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        }
+    };
+    for (int ch = (int)blockIdx.x + (int)gridDim.x * w; ch < nchains; ch += (int)gridDim.x * waves) {
+        const int b = ch / R;
+        float b0 = beta0, b1 = beta1;
+        if (beta_dev) {
+            b0 = beta_dev[2 * b];
+            b1 = beta_dev[2 * b + 1];
+        }
+        const uint32_t row = chain0 + (uint32_t)ch;
+        float thr[NF];
+        unsigned long long sm[NF];
+        // start state s_i = (u < 0.5), draw id `offset`;  F = lin
+#pragma unroll
+        for (int t = 0; t < NF; ++t) {
+            const int i = 64 * t + lane;
+            bool s0 = false;
+            float f0 = 0.f;
+            if (i < n) {
+                const f32x4 u = uniform4(seed, offset, row, (uint32_t)(i >> 2));
+                s0 = u[i & 3] < 0.5f;
+                f0 = lin[(long)b * n + i];
+            }
+            Fw[i] = f0;
+            sm[t] = __ballot(s0);
+        }
+        // initial fields: + J[j, :] for set spins j ascending
+#pragma unroll
+        for (int t = 0; t < NF; ++t) {
+            unsigned long long m = sm[t];
+            while (m) {
+                const int l = __builtin_ctzll(m);
+                m &= m - 1;
+                add_row(rowptr[64 * t + l], rowptr[64 * t + l + 1], 0u);
+            }
+        }
+        const float lr = (sweeps > 1) ? det_logf(b1 / b0) : 0.f;
+        for (int sw = 1; sw <= sweeps; ++sw) {
+            float beta = b1;
+            if (sweeps > 1) beta = b0 * det_expf(lr * ((float)(sw - 1) / (float)(sweeps - 1)));
+            // uniforms and thresholds of this sweep: as in gibbs_chain (one Philox pass serves four tiles)
+            constexpr int NPASS = (NF + 3) / 4;
+            f32x4 ub[NPASS];
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps)
+                ub[ps] = uniform4(seed, offset + (uint64_t)sw, row, (uint32_t)(64 * ps + lane));
+#pragma unroll
+            for (int t = 0; t < NF; ++t) {
+                const int i = 64 * t + lane;
+                const int src = 16 * (t & 3) + (lane >> 2);
+                const float w0 = __shfl(ub[t >> 2][0], src, kWave), w1 = __shfl(ub[t >> 2][1], src, kWave);
+                const float w2 = __shfl(ub[t >> 2][2], src, kWave), w3 = __shfl(ub[t >> 2][3], src, kWave);
+                const int k = lane & 3;
+                const float u = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? w2 : w3;
+                thr[t] = (i < n) ? neg_logit(u) : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < NF; ++t) {
+                const int cnt = min(64, n - 64 * t);
+                const unsigned long long tile = (cnt >= 64) ? ~0ull : (cnt <= 0 ? 0ull : ((1ull << cnt) - 1ull));
+                // (an LDS pointer by type: through a generic volatile pointer the re-read is a FLAT load with the system-coherence
+                // bits set: 7 % of the launch)
+                const volatile __attribute__((address_space(3))) float* Ft =
+                    (const volatile __attribute__((address_space(3))) float*)(Fw + 64 * t + lane);
+                unsigned long long want = (__ballot((beta * *Ft) < thr[t]) ^ sm[t]) & tile;
+                // One flip = readlane (where the row's entries lie, how many) -> ds_read_b64 (lane e: entry e) -> ds_add_f32 into
+                // the neighbours' fields -> ds_read_b32 of the tile's fields -> ballot.  What a flip costs on a wavefront that has
+                // its CU to itself is the NUMBER of instructions (each waits for the one before) rather than the two LDS round trips:
+                // reading the next candidate's entries one flip ahead (one round trip instead of two) took 20 more instructions and
+                // was 40 % SLOWER (profiles/r04_ab_csr_sampler.jsonl).
+                while (want) {
+                    const int l = __builtin_ctzll(want);
+                    const unsigned sgbit = ((sm[t] >> l) & 1ull) ? 0x80000000u : 0u;   // -J if the spin was set
+                    const unsigned info = (unsigned)__builtin_amdgcn_readlane((int)rinfo[t], l);
+                    const unsigned deg = info >> 24;
+                    if (lane < (int)deg) {
+                        const uint2 en = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(s_ent) + (info & 0xffffffu) + 8 * lane);
+                        __hip_atomic_fetch_add(reinterpret_cast<float*>(reinterpret_cast<char*>(Fw) + en.x), __uint_as_float(en.y ^ sgbit),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    }
+                    if (deg > 64u) {   // (a row of more than 64 neighbours: the rest of it)
+                        const int p = 64 * t + l;
+                        add_row(rowptr[p] + 64, rowptr[p + 1], sgbit);
+                    }
+                    sm[t] ^= 1ull << l;
+                    want = (__ballot((beta * *Ft) < thr[t]) ^ sm[t]) & tile & ((~0ull << l) << 1);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NF; ++t) {
+            const int i = 64 * t + lane;
+            if (i < n) states[(long)ch * n + i] = (uint8_t)((sm[t] >> lane) & 1ull);
+        }
+    }
+}
+
 // mean over reads, float64: exact count / R  (np.average(np_samples, axis=0) on {0,1} samples,
 // src/model/faster_dqbm.py:780)
 __global__ __launch_bounds__(256) void k_read_mean(const uint8_t* __restrict__ states, double* __restrict__ mean,
@@ -640,6 +836,48 @@ int launch_gibbs(const float* lin, const float* J, int B, int R, int n, int swee
     return QBM_OK;
 }
 
+// workspace layout of the sparse sampler: [CsrHead | cnt int[n] | rowptr int[n+1] | (pad to 8) | entries uint2[cap]]
+struct CsrLayout {
+    size_t cnt, rowptr, ent, total;
+};
+inline CsrLayout csr_layout(int n, long cap)
+{
+    CsrLayout L;
+    L.cnt = sizeof(CsrHead);
+    L.rowptr = L.cnt + sizeof(int) * (size_t)n;
+    L.ent = (L.rowptr + sizeof(int) * (size_t)(n + 1) + 7) & ~(size_t)7;
+    L.total = L.ent + sizeof(uint2) * (size_t)cap;
+    return L;
+}
+// wavefronts per workgroup and the entries the LDS then holds
+inline int csr_waves(int nch) { const int w = (nch + 255) / 256; return w < 1 ? 1 : w > kCsrMaxWaves ? kCsrMaxWaves : w; }
+inline int csr_nf(int n) { const int NF = (n + 63) / 64; return NF <= 6 ? 6 : NF <= 8 ? 8 : NF <= 10 ? 10 : NF <= 12 ? 12 : 16; }
+inline long csr_lds_cap(int n, int waves) { return ((long)kCsrLdsBytes - 256 - (long)waves * 256 * csr_nf(n)) / 8; }
+
+template <int NF>
+int launch_gibbs_csr(const float* lin, const char* ws, int cap, int B, int R, int n, int sweeps, float beta0, float beta1,
+                     const float* beta_dev, uint64_t seed, uint64_t offset, uint32_t chain0, uint8_t* states, hipStream_t st)
+{
+    const int nch = B * R;
+    const int waves = csr_waves(nch);
+    const long lds_cap = csr_lds_cap(n, waves);
+    const int ent_cap = (int)(cap < lds_cap ? cap : lds_cap);
+    const size_t lds = (size_t)ent_cap * 8 + (size_t)waves * 256 * NF;
+    const CsrLayout L = csr_layout(n, cap);
+    if (lds > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_qubo_gibbs_csr<NF>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_qubo_gibbs_csr)");
+    }
+    int wgs = (nch + waves - 1) / waves;
+    if (wgs > 256) wgs = 256;
+    hipLaunchKernelGGL((k_qubo_gibbs_csr<NF>), dim3(wgs), dim3(64 * waves), lds, st, lin, (const CsrHead*)ws,
+                       (const int*)(ws + L.rowptr), (const uint2*)(ws + L.ent), ent_cap, nch, R, n, sweeps, beta0, beta1, beta_dev,
+                       seed, offset, chain0, states);
+    QBM_CHECK_LAUNCH("k_qubo_gibbs_csr");
+    return QBM_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -697,6 +935,65 @@ int qbm_qubo_gibbs_dev(const float* lin, const float* J, int B, int R, int n, in
     case 9: case 10: rc = launch_gibbs<10>(lin, J, B, R, n, sweeps, beta0, beta1, beta_dev, seed, offset, chain0, states, st); break;
     case 11: case 12: rc = launch_gibbs<12>(lin, J, B, R, n, sweeps, beta0, beta1, beta_dev, seed, offset, chain0, states, st); break;   // conv-QBM QUBOs (n ~ 700)
     default: rc = launch_gibbs<16>(lin, J, B, R, n, sweeps, beta0, beta1, beta_dev, seed, offset, chain0, states, st); break;
+    }
+    if (rc) return rc;
+    if (mean) {
+        hipLaunchKernelGGL(k_read_mean, dim3((B * n + 255) / 256), dim3(256), 0, st, states, mean, B, R, n);
+        QBM_CHECK_LAUNCH("k_read_mean");
+    }
+    return QBM_OK;
+}
+
+long qbm_qubo_csr_max_entries(int n, int chains)
+{
+    if (n <= 0 || n > QBM_MAX_QUBO_VARS || chains <= 0) return 0;
+    return csr_lds_cap(n, csr_waves(chains));
+}
+
+size_t qbm_qubo_csr_workspace_bytes(int n, long cap)
+{
+    if (n <= 0 || n > QBM_MAX_QUBO_VARS || cap < 0) return 0;
+    return csr_layout(n, cap).total;
+}
+
+int qbm_qubo_csr_build(const float* J, int n, long cap, void* workspace, void* stream)
+{
+    if (n <= 0 || n > QBM_MAX_QUBO_VARS) return fail(QBM_ERR_ARG, "qubo_csr_build: n out of range (1..QBM_MAX_QUBO_VARS)");
+    if (cap < 0 || cap > (1l << 24)) return fail(QBM_ERR_ARG, "qubo_csr_build: capacity out of range");
+    if (!J || !workspace) return fail(QBM_ERR_ARG, "qubo_csr_build: null buffer");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const CsrLayout L = csr_layout(n, cap);
+    hipLaunchKernelGGL(k_csr_count, dim3(n), dim3(64), 0, st, J, n, (int*)(ws + L.cnt));
+    QBM_CHECK_LAUNCH("k_csr_count");
+    hipLaunchKernelGGL(k_csr_fill, dim3(n), dim3(64), 0, st, J, n, (const int*)(ws + L.cnt), (CsrHead*)ws, (int*)(ws + L.rowptr),
+                       (uint2*)(ws + L.ent), (int)cap);
+    QBM_CHECK_LAUNCH("k_csr_fill");
+    return QBM_OK;
+}
+
+int qbm_qubo_gibbs_csr(const float* lin, const void* workspace, long cap, int B, int R, int n, int sweeps, const float* beta_dev,
+                       float beta0, float beta1, uint64_t seed, uint64_t offset, uint32_t chain0, uint8_t* states, double* mean,
+                       void* stream)
+{
+    if (B < 0 || R < 0) return fail(QBM_ERR_ARG, "qubo_gibbs_csr: negative batch/reads");
+    if (B == 0 || R == 0) return QBM_OK;
+    if (n <= 0 || n > QBM_MAX_QUBO_VARS) return fail(QBM_ERR_ARG, "qubo_gibbs_csr: n out of range (1..QBM_MAX_QUBO_VARS)");
+    if (sweeps < 0) return fail(QBM_ERR_ARG, "qubo_gibbs_csr: sweeps < 0");
+    if (!beta_dev && (!(beta0 > 0.f) || !(beta1 > 0.f))) return fail(QBM_ERR_ARG, "qubo_gibbs_csr: beta must be positive");
+    if (!lin || !workspace || !states) return fail(QBM_ERR_ARG, "qubo_gibbs_csr: null buffer");
+    if (cap < 0 || cap > (1l << 24)) return fail(QBM_ERR_ARG, "qubo_gibbs_csr: capacity out of range");
+    if (cap > csr_lds_cap(n, csr_waves(B * R)))
+        return fail(QBM_ERR_ARG, "qubo_gibbs_csr: capacity beyond qbm_qubo_csr_max_entries(n, B * R) -- the entries must fit the LDS");
+    hipStream_t st = (hipStream_t)stream;
+    const char* ws = (const char*)workspace;
+    int rc;
+    switch (csr_nf(n)) {
+    case 6: rc = launch_gibbs_csr<6>(lin, ws, (int)cap, B, R, n, sweeps, beta0, beta1, beta_dev, seed, offset, chain0, states, st); break;
+    case 8: rc = launch_gibbs_csr<8>(lin, ws, (int)cap, B, R, n, sweeps, beta0, beta1, beta_dev, seed, offset, chain0, states, st); break;
+    case 10: rc = launch_gibbs_csr<10>(lin, ws, (int)cap, B, R, n, sweeps, beta0, beta1, beta_dev, seed, offset, chain0, states, st); break;
+    case 12: rc = launch_gibbs_csr<12>(lin, ws, (int)cap, B, R, n, sweeps, beta0, beta1, beta_dev, seed, offset, chain0, states, st); break;
+    default: rc = launch_gibbs_csr<16>(lin, ws, (int)cap, B, R, n, sweeps, beta0, beta1, beta_dev, seed, offset, chain0, states, st); break;
     }
     if (rc) return rc;
     if (mean) {

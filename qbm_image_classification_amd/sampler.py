@@ -39,6 +39,26 @@ class HipQuboOps:
                                          ptr(states), ptr(mean), current_stream()), "qbm_qubo_gibbs_ex")
         return states, mean
 
+    def gibbs_csr(self, lin, J, reads, sweeps, beta0=1.0, beta1=1.0, seed=0, offset=0, want_mean=True, chain0=0, cap=None):
+        """gibbs() for SPARSE couplings too wide for the LDS triangle (n > 276): the non-zero entries of J as CSR rows in LDS,
+        the chains' fields beside them (include/qbm_hip.h, "sparse couplings").  -> (states, mean, head): head = int32[2] on the
+        device, (status, non-zero couplings found); status 1 = more than `cap` (default: what the LDS holds) and NOTHING was
+        sampled -- the caller falls back to gibbs().  States are bit-identical to gibbs() on the same arguments."""
+        lin = lin.to(self.device, torch.float32).contiguous()
+        J = J.to(self.device, torch.float32).contiguous()
+        B, n = lin.shape
+        if J.shape != (n, n):
+            raise _lib.QbmHipError(f"J must be [{n},{n}], got {tuple(J.shape)}")
+        lim = int(self.lib.qbm_qubo_csr_max_entries(n, max(1, B * reads)))
+        cap = lim if cap is None else int(cap)
+        ws = torch.empty(int(self.lib.qbm_qubo_csr_workspace_bytes(n, cap)) // 4, dtype=torch.int32, device=self.device)
+        states = torch.empty(B, reads, n, dtype=torch.uint8, device=self.device)
+        mean = torch.empty(B, n, dtype=torch.float64, device=self.device) if want_mean else None
+        check(self.lib.qbm_qubo_csr_build(ptr(J), n, cap, ptr(ws), current_stream()), "qbm_qubo_csr_build")
+        check(self.lib.qbm_qubo_gibbs_csr(ptr(lin), ptr(ws), cap, B, reads, n, sweeps, None, beta0, beta1, seed, offset, int(chain0),
+                                          ptr(states), ptr(mean), current_stream()), "qbm_qubo_gibbs_csr")
+        return states, mean, ws[:2]
+
     # ---- device-resident Disc_QBM state: theta = [W_vh (1+D)*H | W_vo D | b_h H | b_o 1] float64 (include/qbm_hip.h) ----
     def linear_fields_dev(self, X, labels, theta, D, H, beta_eff=1.0):
         """x-dependent QUBO diagonal with the parameters read from the device buffer theta -> lin fp32 [B,n]."""
@@ -152,6 +172,8 @@ class HipGibbsSampler:
         self.seed = 0 if seed is None else int(seed)
         self.beta_range = None if beta_range is None else (float(beta_range[0]), float(beta_range[1]))
         self._calls = 0
+        self.sparse = True  # wide QUBOs (n > 276): try the CSR-in-LDS kernel first (False: always the dense kernel; same samples)
+        self.last_kernel = None
         self._bufs = {}     # (n, dtype, reads) -> staging and device buffers, kept from call to call
 
     def _buffers(self, n, dtype, reads):
@@ -166,7 +188,11 @@ class HipGibbsSampler:
                 q_pin=torch.empty(n * n, dtype=dtype).pin_memory(), q_dev=f(n * n, dt=dtype), lin=f(1, n), J=f(n, n),
                 rowabs=f(n, dt=torch.float64), rowmin=f(n, dt=torch.float64), any_off=torch.zeros(1, dtype=torch.int32, device=dev),
                 beta=f(1, 2), states=torch.empty(1, reads, n, dtype=torch.uint8, device=dev), out=f(reads, n),
-                out_pin=torch.empty(reads, n, dtype=torch.float32).pin_memory(), flag_pin=torch.zeros(1, dtype=torch.int32).pin_memory())
+                out_pin=torch.empty(reads, n, dtype=torch.float32).pin_memory(), flag_pin=torch.zeros(2, dtype=torch.int32).pin_memory(),
+                csr=None, cap=0)
+            if n > 276:   # (the triangle of J no longer fits a CU's LDS: qubo_kernels.hip, launch_gibbs)
+                b["cap"] = int(self.ops.lib.qbm_qubo_csr_max_entries(n, reads))
+                b["csr"] = torch.zeros(int(self.ops.lib.qbm_qubo_csr_workspace_bytes(n, b["cap"])) // 4, dtype=torch.int32, device=dev)
             if self.beta_range is not None:
                 b["beta"].copy_(torch.tensor([self.beta_range], dtype=torch.float32))
             b["q_np"] = b["q_pin"].numpy().reshape(n, n)
@@ -190,12 +216,30 @@ class HipGibbsSampler:
                                   ptr(b["any_off"]), st), "qbm_qubo_from_Q")
         if self.beta_range is None:   # hot / cold from the QUBO's coefficients, on the device (auto_beta_range is the host statement)
             check(lib.qbm_qbm_beta_range(ptr(b["lin"]), ptr(b["rowabs"]), ptr(b["rowmin"]), 1, n, ptr(b["beta"]), st), "qbm_qbm_beta_range")
-        check(lib.qbm_qubo_gibbs_dev(ptr(b["lin"]), ptr(b["J"]), 1, reads, n, self.num_sweeps, ptr(b["beta"]), 1.0, 1.0, self.seed,
-                                     self._calls << 20, 0, ptr(b["states"]), None, st), "qbm_qubo_gibbs_dev")
+        dense = lambda: check(lib.qbm_qubo_gibbs_dev(ptr(b["lin"]), ptr(b["J"]), 1, reads, n, self.num_sweeps, ptr(b["beta"]), 1.0, 1.0,
+                                                     self.seed, self._calls << 20, 0, ptr(b["states"]), None, st), "qbm_qubo_gibbs_dev")
+        sparse = b["csr"] is not None and self.sparse
+        if sparse:
+            # too wide for the LDS triangle: the non-zero couplings as CSR rows in LDS (a conv-QBM QUBO holds 1 % of them) -- the
+            # same states bit for bit, at a fraction of a flip's cost.  Whether they fit is known on the device only: the status
+            # word comes back with the samples, and a matrix that does not fit is sampled again by the dense kernel below.
+            check(lib.qbm_qubo_csr_build(ptr(b["J"]), n, b["cap"], ptr(b["csr"]), st), "qbm_qubo_csr_build")
+            check(lib.qbm_qubo_gibbs_csr(ptr(b["lin"]), ptr(b["csr"]), b["cap"], 1, reads, n, self.num_sweeps, ptr(b["beta"]), 1.0, 1.0,
+                                         self.seed, self._calls << 20, 0, ptr(b["states"]), None, st), "qbm_qubo_gibbs_csr")
+            b["flag_pin"][1:2].copy_(b["csr"][:1], non_blocking=True)
+        else:
+            dense()
         check(lib.qbm_u8_to_f32(ptr(b["states"]), ptr(b["out"]), reads * n, st), "qbm_u8_to_f32")
         b["out_pin"].copy_(b["out"], non_blocking=True)
-        b["flag_pin"].copy_(b["any_off"], non_blocking=True)
+        b["flag_pin"][0:1].copy_(b["any_off"], non_blocking=True)
         torch.cuda.current_stream().synchronize()                         # the call's one synchronisation
+        self.last_kernel = "csr" if sparse else "dense"
+        if sparse and int(b["flag_pin"][1]) != 0 and int(b["flag_pin"][0]) != 0:
+            dense()                                                       # (more couplings than the LDS holds: the second and last try)
+            check(lib.qbm_u8_to_f32(ptr(b["states"]), ptr(b["out"]), reads * n, st), "qbm_u8_to_f32")
+            b["out_pin"].copy_(b["out"], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            self.last_kernel = "dense"
         self._calls += 1
         if int(b["flag_pin"][0]) == 0:
             # the reference short-circuits a QUBO without quadratic terms (src/qubo/sampler.py:13-17, 28-29):

@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, s), f"{s} declared in qbm_hip.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
     assert set(_lib.SIGNATURES) == set(syms)
-    assert lib.qbm_abi_version() == _lib.QBM_ABI_VERSION == 14
+    assert lib.qbm_abi_version() == _lib.QBM_ABI_VERSION == 15
 
 
 def test_argument_validation_without_a_gpu(lib):

@@ -518,6 +518,77 @@ def test_qubo_gibbs_bitwise(oracle):
         assert np.array_equal(mean.cpu().numpy(), mo), "mean over reads (float64: exact count / R)"
 
 
+def _sparse_qubo(rs, n, deg, scale=0.5, hub=None):
+    """symmetric J [n,n] with about `deg` neighbours per spin (+ one spin coupled to `hub` others)"""
+    J = np.zeros((n, n), np.float32)
+    for i in range(n):
+        for j in rs.choice(n, size=max(1, deg // 2), replace=False):
+            if i != j:
+                J[i, j] = J[j, i] = np.float32(rs.standard_normal() * scale)
+    if hub:
+        h = n // 3
+        for j in rs.choice(n, size=hub, replace=False):
+            if j != h:
+                J[h, j] = J[j, h] = np.float32(rs.standard_normal() * scale)
+    return J
+
+
+def test_qubo_gibbs_csr_bitwise(oracle):
+    """The sparse-coupling sampler (CSR rows and the chains' fields in LDS, ds_add_f32 into the neighbours' fields: round 4)
+    against the oracle and against the dense kernel, bit for bit: one to eight wavefronts per workgroup (the chain count
+    picks), rows of more than 64 neighbours, a ragged last tile, every tile count the kernel is built for (n = 60 ... 1024),
+    an empty row, chain0 (sharded minibatches); couplings and fields in the DENORMAL range (the LDS atomic must neither flush
+    nor round them differently from fmaf(+-1, J, F)); the overflow protocol (more couplings than `cap`: status 1, nothing
+    sampled, the dense kernel takes over)."""
+    from qbm_image_classification_amd.sampler import HipQuboOps
+
+    q = HipQuboOps("cuda:0")
+    rs = np.random.RandomState(12)
+    for (B, R, n, deg, hub, sweeps, b0, b1, chain0) in [(1, 5, 300, 8, None, 4, 0.5, 2.0, 0), (2, 40, 384, 6, 100, 3, 0.3, 3.0, 0),
+                                                        (1, 100, 717, 8, 40, 3, 0.2, 2.5, 0), (3, 200, 520, 10, 70, 2, 0.5, 1.5, 0),
+                                                        (1, 9, 1024, 12, 200, 2, 1.0, 1.0, 0), (2, 6, 60, 4, 30, 5, 0.4, 2.0, 0),
+                                                        (30, 100, 330, 6, None, 2, 0.3, 2.0, 0), (2, 33, 650, 8, 65, 3, 0.3, 2.0, 17),
+                                                        (1, 12, 897, 8, None, 2, 0.5, 1.5, 0)]:
+        lin = rs.standard_normal((B, n)).astype(np.float32)
+        J = _sparse_qubo(rs, n, deg, hub=hub)
+        J[5, :] = 0
+        J[:, 5] = 0                                      # a spin without neighbours
+        lt, Jt = torch.from_numpy(lin).cuda(), torch.from_numpy(J).cuda()
+        st, mean, head = q.gibbs_csr(lt, Jt, R, sweeps, b0, b1, 77, 5, True, chain0)
+        assert head.cpu().tolist() == [0, int(np.count_nonzero(J))]
+        sd, md = q.gibbs(lt, Jt, R, sweeps, b0, b1, 77, 5, True, chain0)
+        assert torch.equal(st, sd) and torch.equal(mean, md), f"sparse and dense kernels differ for n={n}"
+        if B * R * n <= 200000:
+            so, mo = oracle.qubo_gibbs(lin, J, R, sweeps, b0, b1, 77, 5, chain0)
+            assert np.array_equal(st.cpu().numpy(), so), f"states differ for n={n}"
+            assert np.array_equal(mean.cpu().numpy(), mo)
+    # denormal couplings and fields (beta large enough for them to decide spins)
+    n = 320
+    J = (_sparse_qubo(rs, n, 8, scale=1.0).astype(np.float64) * 2.5e-39).astype(np.float32)
+    lin = (rs.standard_normal((2, n)) * 2.5e-39).astype(np.float32)
+    assert J[J != 0].size > 2000 and np.abs(J[J != 0]).max() < 1.17549435e-38
+    st, _, head = q.gibbs_csr(torch.from_numpy(lin).cuda(), torch.from_numpy(J).cuda(), 6, 5, 3e38, 3e38, 4, 2)
+    so, _ = oracle.qubo_gibbs(lin, J, 6, 5, 3e38, 3e38, 4, 2)
+    sz, _ = oracle.qubo_gibbs(lin * 0, J * 0, 6, 5, 3e38, 3e38, 4, 2)
+    assert not np.array_equal(so, sz), "(the denormal terms decide spins: flushing them would show)"
+    assert head[0].item() == 0 and np.array_equal(st.cpu().numpy(), so), "denormal couplings"
+    # overflow: a dense matrix does not fit; nothing is written, the dense kernel is the fallback
+    n = 400
+    Ju = np.triu(rs.standard_normal((n, n)).astype(np.float32) * 0.1, 1)
+    J = torch.from_numpy((Ju + Ju.T).astype(np.float32)).cuda()
+    lin = torch.from_numpy(rs.standard_normal((1, n)).astype(np.float32)).cuda()
+    lim = q.lib.qbm_qubo_csr_max_entries(n, 8)
+    assert 15000 < lim < n * (n - 1)
+    st, mean, head = q.gibbs_csr(lin, J, 8, 2, 1.0, 1.0, 1, 0)
+    assert head.cpu().tolist() == [1, n * (n - 1)]
+    st2, _, head2 = q.gibbs_csr(lin, J * (torch.rand_like(J) < 0.0), 8, 2, 1.0, 1.0, 1, 0, cap=0)   # no couplings at all, cap 0
+    assert head2.cpu().tolist() == [0, 0]
+    so, _ = oracle.qubo_gibbs(lin.cpu().numpy(), np.zeros((n, n), np.float32), 8, 2, 1.0, 1.0, 1, 0)
+    assert np.array_equal(st2.cpu().numpy(), so)
+    with pytest.raises(Exception):
+        q.gibbs_csr(lin, J, 8, 2, 1.0, 1.0, 1, 0, cap=lim + 1)
+
+
 def test_qubo_gibbs_sharding_invariance(oracle):
     """Rows [lo, hi) of a minibatch sampled with chain0 = lo * R are exactly the rows [lo, hi) of the whole call (what a
     data-parallel rank of Disc_QBM does), on both kernels (LDS-resident triangle and J rows from L2)."""
@@ -764,7 +835,16 @@ def test_sample_q_on_reference_conv_qbm_qubo(oracle):
                 st, _ = q.gibbs(torch.from_numpy(lin).cuda(), torch.from_numpy(J).cuda(), 8, 6, b0, b1, 3, 1)
                 so, _ = oracle.qubo_gibbs(lin, J, 8, 6, b0, b1, 3, 1)
                 assert np.array_equal(st.cpu().numpy(), so)
-            S = HipGibbsSampler(num_sweeps=1000, seed=7).sample_Q(Q.astype(np.float64), 64)
+                # ... and so does the sparse kernel sample_Q picks for it (round 4: its 5762 couplings as CSR rows in LDS)
+                sc, _, head = q.gibbs_csr(torch.from_numpy(lin).cuda(), torch.from_numpy(J).cuda(), 8, 6, b0, b1, 3, 1)
+                assert head.cpu().tolist() == [0, int(np.count_nonzero(J))] and np.array_equal(sc.cpu().numpy(), so)
+            smp = HipGibbsSampler(num_sweeps=1000, seed=7)
+            S = smp.sample_Q(Q.astype(np.float64), 64)
+            assert smp.last_kernel == "csr"
+            if img == 0:   # the same samples from the dense kernel
+                smd = HipGibbsSampler(num_sweeps=1000, seed=7)
+                smd.sparse = False
+                assert np.array_equal(smd.sample_Q(Q.astype(np.float64), 64), S) and smd.last_kernel == "dense"
             assert S.shape == (64, n) and S.dtype == np.float32 and set(np.unique(S)) <= {0.0, 1.0}
             E, amo, link = _cdqbm_analyse(g, Q, S)
             So, _ = oracle.qubo_gibbs(lin, J, 8, 5000, b0, b1, 5, 0)

@@ -30,6 +30,7 @@ def conv_lines(a):
         n = Q.shape[0]
         for sweeps in a.sweeps:
             smp = HipGibbsSampler(num_sweeps=sweeps, seed=7)
+            smp.sparse = not a.dense
             smp.sample_Q(Q, a.reads)
             best = float("inf")
             for _ in range(a.reps):
@@ -39,7 +40,7 @@ def conv_lines(a):
                 best = min(best, time.perf_counter() - t0)
             e = np.einsum("ri,ij,rj->r", s.astype(np.float64), Q, s.astype(np.float64))
             print(json.dumps({"what": f"sample_Q, conv-QBM {key} n = {n} ({int((Q != 0).sum())} non-zeros), {a.reads} reads, {sweeps} sweeps, host call",
-                              "ms_per_call": round(best * 1e3, 3), "spin_updates_per_s": round(a.reads * sweeps * n / best, 1),
+                              "kernel": smp.last_kernel, "ms_per_call": round(best * 1e3, 3), "spin_updates_per_s": round(a.reads * sweeps * n / best, 1),
                               "energy_min": round(float(e.min()), 4), "energy_mean": round(float(e.mean()), 4)}), flush=True)
 
 
@@ -51,6 +52,7 @@ def main():
     ap.add_argument("--images", type=int, default=73)
     ap.add_argument("--reads", type=int, default=100)
     ap.add_argument("--conv", action="store_true", help="sample_Q on the conv-QBM QUBOs of tests/golden/cdqbm_qubo.npz (n = 716 / 717) instead")
+    ap.add_argument("--dense", action="store_true", help="--conv: the dense kernel (J rows from L2) instead of the CSR-in-LDS one")
     a = ap.parse_args()
     if a.conv:
         return conv_lines(a)
