@@ -428,6 +428,12 @@ QBM_API int qbm_qbm_beta_range(const float* lin, const double* rowabs, const dou
 QBM_API int qbm_qbm_stats_diff(const double* X, const int32_t* labels, const double* mean_c, const double* mean_u, int B,
                                int D, int H, double* diff, void* stream);
 
+/* The same with one more output: diff[theta length] = the sum over the images of compute_nll's per-image term
+ * (src/model/faster_dqbm.py:986-991: -log(float32([1 - p1, p1])[y] + 1e-12), p1 = mean_u[i,0]); float32 terms, float64 sum in
+ * image order.  diff holds qbm theta length + 1 doubles. */
+QBM_API int qbm_qbm_stats_diff_nll(const double* X, const int32_t* labels, const double* mean_c, const double* mean_u, int B,
+                                   int D, int H, double* diff, void* stream);
+
 /* theta -= lr * (diff / batch), src/model/faster_dqbm.py:1041-1059 (batch = the GLOBAL minibatch size when diff was
  * all-reduced over data-parallel ranks). */
 QBM_API int qbm_qbm_apply_update(double* theta, const double* diff, int D, int H, double lr, double batch, void* stream);

@@ -103,6 +103,7 @@ SIGNATURES = {
     "qbm_qbm_couplings": [_p, _p, _i, _i, C.c_double, _p, _p, _p, _p],
     "qbm_qbm_beta_range": [_p, _p, _p, _i, _i, _p, _p],
     "qbm_qbm_stats_diff": [_p, _p, _p, _p, _i, _i, _i, _p, _p],
+    "qbm_qbm_stats_diff_nll": [_p, _p, _p, _p, _i, _i, _i, _p, _p],
     "qbm_qbm_apply_update": [_p, _p, _i, _i, C.c_double, C.c_double, _p],
     "qbm_qbm_batch_stats": [_p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p],
     "qbm_qbm_linear_fields": [_p, _p, _p, _p, _p, C.c_double, _i, _i, _i, C.c_double, _p, _p],

@@ -59,7 +59,9 @@ struct JTri {
         for (int tt = 0; tt < NFT; ++tt) {
             const int i = min(64 * tt + lane, n - 1);
             ic[tt] = 4 * i;
-            ci[tt] = 4 * (i * n - (i * (i - 1)) / 2 - i);
+            // (+ the triangle's LDS address: every read below adds ci -- or `up`, which is some lane's ci -- exactly once, so the
+            // address needs no further add; `tri + offset` cost one v_add_u32 per flip for a base the linker resolves to 0)
+            ci[tt] = 4 * (i * n - (i * (i - 1)) / 2 - i) + (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)tri;
         }
     }
     template <int T, int NF>
@@ -71,7 +73,6 @@ struct JTri {
         // wavefronts one scalar and one vector slot every 4 cycles), not by latency: two chains in lockstep in one wavefront,
         // same count per flip plus null steps, were 18 % SLOWER
         const int up = __builtin_amdgcn_readlane(ci[T], p & 63), p4 = 4 * p;
-        const char* base = reinterpret_cast<const char*>(tri);
         // the later tiles lie 256 bytes apart behind ONE address (up + 4 lane): immediate offsets, and the compiler pairs the
         // reads (ds_read2st64_b32).  Phantom lanes of the last tile read up to 252 bytes beyond the row -- the next rows, or the
         // 256 zeroed bytes the kernel keeps behind the triangle: finite values for fields nobody tests.
@@ -81,8 +82,10 @@ struct JTri {
             int ad;
             if (tt < T) ad = ci[tt] + p4;                // every spin of an earlier tile is below p
             else if (tt > T) ad = rb + 256 * tt;         // every spin of a later tile is above p
-            else ad = (ic[tt] >= p4) ? up + ic[tt] : ci[tt] + p4;
-            out[tt] = *reinterpret_cast<const float*>(base + ad);
+            else ad = min(up + ic[tt], ci[tt] + p4);     // the spin's own tile: T(min(i, p), max(i, p)) is the SMALLER of the two
+                                                         // candidates (S(r) - r grows by n - 1 - r >= 1 words per row, a column
+                                                         // by one): a v_min instead of a compare and a select
+            out[tt] = *(__attribute__((address_space(3))) const float*)(uintptr_t)(uint32_t)ad;
         }
     }
 };
@@ -241,7 +244,10 @@ __device__ __forceinline__ void gibbs_chain(const float* __restrict__ lin, const
                 row_of_tile<NF>(jr, t, 64 * t + l, lane, jrow);
 #pragma unroll
                 for (int tt = 0; tt < NF; ++tt) F[tt] = __builtin_fmaf(sg, jrow[tt], F[tt]);
-                if constexpr (XS) Fx = __builtin_fmaf(sg, __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(jx[t]), l)), Fx);
+                // (fl(Fx +- j) is what fmaf(+-1, j, Fx) rounds to: the sign goes into j on the scalar unit -- one vector add, and no
+                // v_mov to get a second scalar operand into a vector register)
+                if constexpr (XS)
+                    Fx = Fx + __uint_as_float((uint32_t)__builtin_amdgcn_readlane(__float_as_uint(jx[t]), l) ^ (__float_as_uint(sg) & 0x80000000u));
                 sm[t] ^= 1ull << l;
                 if (all_full || full) {
                     want = (__ballot((beta * F[t]) < thr[t]) ^ sm[t]) & ((~0ull << l) << 1);   // the spins behind l
@@ -577,59 +583,80 @@ __global__ __launch_bounds__(256) void k_batch_stats(const double* __restrict__ 
 
 // x-dependent part of create_qubo_matrix_from (src/model/faster_dqbm.py:236-245, 273-283): float64,
 // sequential over k, one thread per (image, variable); rounded to fp32 for the sampler.
-__global__ __launch_bounds__(64) void k_linear_fields(const double* __restrict__ X, const int* __restrict__ labels,
-                                                       const double* __restrict__ W_vh, const double* __restrict__ W_vo,
-                                                       const double* __restrict__ b_h, double b_o_val,
-                                                       const double* __restrict__ b_o_dev, int B, int D, int H,
-                                                       double beta_eff, float* __restrict__ lin)
+// Round 4: the sum is a chain of 2 D dependent float64 operations per output -- 5 us of arithmetic at D = 784 -- but with one
+// thread per output fetching its own operands the kernel waited for a round trip to L2 per 8 terms: 58 us, twice per training
+// minibatch.  Now a workgroup owns 64 variables x 4 images (one wavefront per image): the weights of its 64 columns and the
+// pixels of its 4 images pass through LDS in chunks of 56 terms, the next three chunks on their way (42 loads per thread in
+// flight) while the current one is summed: operands come from LDS (the pixel is one broadcast read, the weights 512 contiguous bytes).
+// Same terms, same order, product then sum.
+constexpr int kLfKC = 56, kLfIm = 4;
+__global__ __launch_bounds__(64 * kLfIm) void k_linear_fields(const double* __restrict__ X, const int* __restrict__ labels,
+                                                              const double* __restrict__ W_vh, const double* __restrict__ W_vo,
+                                                              const double* __restrict__ b_h, double b_o_val,
+                                                              const double* __restrict__ b_o_dev, int B, int D, int H,
+                                                              double beta_eff, float* __restrict__ lin)
 {
+    __shared__ double wbuf[2][kLfKC][64];
+    __shared__ double xbuf[2][kLfIm][kLfKC];
     const double b_o = b_o_dev ? b_o_dev[0] : b_o_val;   // device-resident parameters: the output bias by address
     const int n = labels ? H : H + 1;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * n) return;
-    const int i = idx / n, v = idx % n;
-    const double* x = X + (long)i * D;
-    double a = 0.0;
-    if (!labels && v == 0) {
-        int k = 0;
-        for (; k + 8 <= D; k += 8) {
-            double xv[8], wv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { xv[u] = x[k + u]; wv[u] = W_vo[k + u]; }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) a += xv[u] * wv[u];
-        }
-        for (; k < D; ++k) a += x[k] * W_vo[k];
-        lin[idx] = (float)((b_o + a) / beta_eff);
-        return;
-    }
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int v = 64 * (int)blockIdx.x + lane;            // this lane's variable: the column it stages AND the one it sums
+    const int i = kLfIm * (int)blockIdx.y + w;            // this wavefront's image
+    const bool outnode = !labels && v == 0;               // unclamped variable 0 = the output node: its "column" is W_vo
     const int j = labels ? v : v - 1;
-    if (labels) a += (double)labels[i] * W_vh[j];
-    // the sum runs over k in ascending order (product, then sum); the operands of 8 terms are requested together so that
-    // their latencies overlap instead of adding up
-    const double* w = W_vh + (long)H + j;
-    int k = 0;
-    // ... and the next 8 are requested before the current 8 are added up (the chain of 2 D dependent float64 operations is
-    // what the kernel should wait for, not a round trip to L2 per group of 8)
-    constexpr int G = 8;
-    if (D >= 2 * G) {
-        double xv[G], wv[G], xn[G], wn[G];
+    const double* wcol = outnode ? W_vo : W_vh + (long)H + j;   // term k: wcol[k * wstride]
+    const long wstride = outnode ? 1 : H;
+    constexpr int NR = kLfKC / kLfIm;                     // rows of a chunk each thread stages (its own column: k = w + 4 r)
+    const int xi = tid / kLfKC, xk = tid % kLfKC;         // the pixel it stages (threads 0 .. 4 KC - 1)
+    const int ximg = kLfIm * (int)blockIdx.y + xi;
+    // kLfAhead chunks are in flight at any time (registers are where they land: a chunk's loads are issued kLfAhead - 1
+    // iterations before it is written to LDS -- one chunk is summed in 0.6 us, a first touch of the weights takes ~2 us)
+    constexpr int kLfAhead = 4;
+    double wr[kLfAhead][NR], xr[kLfAhead];
+    auto fetch = [&](int slot, int k0) {
 #pragma unroll
-        for (int u = 0; u < G; ++u) { xv[u] = x[u]; wv[u] = w[(long)u * H]; }
-        for (; k + 2 * G <= D; k += G) {
-#pragma unroll
-            for (int u = 0; u < G; ++u) { xn[u] = x[k + G + u]; wn[u] = w[(long)(k + G + u) * H]; }
-#pragma unroll
-            for (int u = 0; u < G; ++u) a += xv[u] * wv[u];
-#pragma unroll
-            for (int u = 0; u < G; ++u) { xv[u] = xn[u]; wv[u] = wn[u]; }
+        for (int r = 0; r < NR; ++r) {
+            const int k = k0 + w + kLfIm * r;
+            wr[slot][r] = (v < n && k < D) ? wcol[(long)k * wstride] : 0.0;
         }
+        xr[slot] = (tid < kLfIm * kLfKC && ximg < B && k0 + xk < D) ? X[(long)ximg * D + k0 + xk] : 0.0;
+    };
+    auto stash = [&](int slot, int buf) {
 #pragma unroll
-        for (int u = 0; u < G; ++u) a += xv[u] * wv[u];
-        k += G;
+        for (int r = 0; r < NR; ++r) wbuf[buf][w + kLfIm * r][lane] = wr[slot][r];
+        if (tid < kLfIm * kLfKC) xbuf[buf][xi][xk] = xr[slot];
+    };
+    double a = 0.0;
+    if (labels && v < n && i < B) a += (double)labels[i] * W_vh[j];
+    const int nc = (D + kLfKC - 1) / kLfKC;
+#pragma unroll
+    for (int u = 0; u < kLfAhead - 1; ++u)
+        if (u < nc) fetch(u, u * kLfKC);
+    stash(0, 0);
+    __syncthreads();
+    for (int c0 = 0; c0 < nc; c0 += kLfAhead) {
+#pragma unroll
+        for (int u = 0; u < kLfAhead; ++u) {     // (chunk c = c0 + u lives in register slot u: the slots are compile-time)
+            const int c = c0 + u;
+            if (c >= nc) break;
+            const int cur = c & 1;
+            if (c + kLfAhead - 1 < nc) fetch((u + kLfAhead - 1) % kLfAhead, (c + kLfAhead - 1) * kLfKC);
+            const int kmax = min(kLfKC, D - c * kLfKC);
+            int kk = 0;
+            for (; kk + 8 <= kmax; kk += 8) {
+                double xv[8], wv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { xv[q] = xbuf[cur][w][kk + q]; wv[q] = wbuf[cur][kk + q][lane]; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) a += xv[q] * wv[q];
+            }
+            for (; kk < kmax; ++kk) a += xbuf[cur][w][kk] * wbuf[cur][kk][lane];
+            if (c + 1 < nc) stash((u + 1) % kLfAhead, cur ^ 1);
+            __syncthreads();
+        }
     }
-    for (; k < D; ++k) a += x[k] * w[(long)k * H];
-    lin[idx] = (float)((b_h[j] + a) / beta_eff);
+    if (v < n && i < B) lin[(long)i * n + v] = (float)(((outnode ? b_o : b_h[j]) + a) / beta_eff);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -758,10 +785,23 @@ __global__ __launch_bounds__(64) void k_qbm_beta(const float* __restrict__ lin, 
 __global__ __launch_bounds__(256) void k_qbm_stats_diff(const double* __restrict__ X, const int* __restrict__ labels,
                                                         const double* __restrict__ mean_c /* [B,H] */,
                                                         const double* __restrict__ mean_u /* [B,1+H] */, int B, int D,
-                                                        int H, double* __restrict__ diff)
+                                                        int H, double* __restrict__ diff, int with_nll)
 {
     const long nW = (long)(1 + D) * H;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (with_nll && idx == nW + D + H + 1) {
+        // diff[theta length] = sum over the images of compute_nll's term (src/model/faster_dqbm.py:986-991):
+        // -log(float32([1 - p1, p1])[y] + 1e-12), p1 = mean of the output node; float32 terms, float64 sum in image order
+        // (a monitor, compared with a tolerance: a dozen small torch launches per minibatch until round 4)
+        double sum = 0.0;
+        for (int i = 0; i < B; ++i) {
+            const double p1 = mean_u[(long)i * (H + 1)];
+            const float p = (float)(labels[i] ? p1 : 1.0 - p1);
+            sum += (double)(-logf(p + 1e-12f));
+        }
+        diff[idx] = sum;
+        return;
+    }
     if (idx >= nW + D + H + 1) return;
     const int nu = H + 1;
     double c = 0.0, u = 0.0;
@@ -1074,7 +1114,20 @@ int qbm_qbm_stats_diff(const double* X, const int32_t* labels, const double* mea
     if (!diff || (B > 0 && (!X || !labels || !mean_c || !mean_u))) return fail(QBM_ERR_ARG, "stats_diff: null buffer");
     const long total = qbm_theta_len(D, H);
     hipLaunchKernelGGL(k_qbm_stats_diff, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, labels,
-                       mean_c, mean_u, B, D, H, diff);
+                       mean_c, mean_u, B, D, H, diff, 0);
+    QBM_CHECK_LAUNCH("k_qbm_stats_diff");
+    return QBM_OK;
+}
+
+int qbm_qbm_stats_diff_nll(const double* X, const int32_t* labels, const double* mean_c, const double* mean_u, int B, int D,
+                           int H, double* diff, void* stream)
+{
+    if (B < 0) return fail(QBM_ERR_ARG, "stats_diff_nll: B < 0");
+    if (D <= 0 || H <= 0) return fail(QBM_ERR_ARG, "stats_diff_nll: non-positive dims");
+    if (!diff || (B > 0 && (!X || !labels || !mean_c || !mean_u))) return fail(QBM_ERR_ARG, "stats_diff_nll: null buffer");
+    const long total = qbm_theta_len(D, H) + 1;
+    hipLaunchKernelGGL(k_qbm_stats_diff, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, labels,
+                       mean_c, mean_u, B, D, H, diff, 1);
     QBM_CHECK_LAUNCH("k_qbm_stats_diff");
     return QBM_OK;
 }
@@ -1103,8 +1156,8 @@ int qbm_qbm_linear_fields_dev(const double* X, const int32_t* labels, const doub
     const double* W_vo = W_vh + (long)(1 + D) * H;
     const double* b_h = W_vo + D;
     const int n = labels ? H : H + 1;
-    hipLaunchKernelGGL(k_linear_fields, dim3((B * n + 63) / 64), dim3(64), 0, (hipStream_t)stream, X, labels, W_vh,
-                       W_vo, b_h, 0.0, b_h + H, B, D, H, beta_eff, lin);
+    hipLaunchKernelGGL(k_linear_fields, dim3((n + 63) / 64, (B + kLfIm - 1) / kLfIm), dim3(64 * kLfIm), 0, (hipStream_t)stream, X, labels,
+                       W_vh, W_vo, b_h, 0.0, b_h + H, B, D, H, beta_eff, lin);
     QBM_CHECK_LAUNCH("k_linear_fields");
     return QBM_OK;
 }
@@ -1119,8 +1172,8 @@ int qbm_qbm_linear_fields(const double* X, const int32_t* labels, const double* 
     if (!X || !W_vh || !W_vo || !b_h || !lin) return fail(QBM_ERR_ARG, "linear_fields: null buffer");
     if (beta_eff == 0.0) return fail(QBM_ERR_ARG, "linear_fields: beta_eff == 0");
     const int n = labels ? H : H + 1;
-    hipLaunchKernelGGL(k_linear_fields, dim3((B * n + 63) / 64), dim3(64), 0, (hipStream_t)stream, X, labels, W_vh,
-                       W_vo, b_h, b_o, (const double*)nullptr, B, D, H, beta_eff, lin);
+    hipLaunchKernelGGL(k_linear_fields, dim3((n + 63) / 64, (B + kLfIm - 1) / kLfIm), dim3(64 * kLfIm), 0, (hipStream_t)stream, X, labels,
+                       W_vh, W_vo, b_h, b_o, (const double*)nullptr, B, D, H, beta_eff, lin);
     QBM_CHECK_LAUNCH("k_linear_fields");
     return QBM_OK;
 }

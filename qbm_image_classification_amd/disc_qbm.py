@@ -400,17 +400,6 @@ class Disc_QBM:
             total += float(-log_probs[int(y)])
         return total / len(p1)
 
-    @staticmethod
-    def _nll_sum(mean_u, labels):
-        """Sum over the images of compute_nll's per-image term (:986-991), as a float64 scalar on mean_u's device:
-        -log(float32([1 - p1, p1])[y] + 1e-12) with p1 = mean of the output node."""
-        import torch
-
-        p1 = mean_u[:, 0]
-        probs = torch.stack([1.0 - p1, p1], dim=1).to(torch.float32)
-        lp = torch.log(probs + 1e-12)
-        return (-lp.gather(1, labels.long().view(-1, 1))).double().sum()
-
     def _step_device(self, X, labels, learning_rate):
         """One training iteration with every array on the device (src/model/faster_dqbm.py:998-1064):
         -> (error of the output bias, average NLL) as 0-dim float64 device tensors.  With a data-parallel group every rank
@@ -426,8 +415,7 @@ class Disc_QBM:
         D, H = self.dim_input, self.n_hidden_nodes
         buf = torch.zeros(self._theta_len() + 1, dtype=torch.float64, device=self.ops.device)   # [diff (theta layout) | NLL sum]
         if hi > lo:
-            self.ops.stats_diff(X[lo:hi], labels[lo:hi], mean_c, mean_u, D, H, buf)
-            buf[-1] = self._nll_sum(mean_u, labels[lo:hi])
+            self.ops.stats_diff(X[lo:hi], labels[lo:hi], mean_c, mean_u, D, H, buf, nll=True)   # (the NLL sum from the same launch)
         if world > 1 or self._dp is True:   # (data_parallel=True on a one-rank group: the same code path, a one-rank all-reduce)
             import torch.distributed as dist
 

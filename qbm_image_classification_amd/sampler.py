@@ -96,10 +96,12 @@ class HipQuboOps:
                                           ptr(states), ptr(mean), current_stream()), "qbm_qubo_gibbs_dev")
         return states, mean
 
-    def stats_diff(self, X, labels, mean_c, mean_u, D, H, out):
-        """out[theta layout] = statistics(clamped) - statistics(unclamped) of the images given."""
-        check(self.lib.qbm_qbm_stats_diff(ptr(X), ptr(labels), ptr(mean_c), ptr(mean_u), X.shape[0], D, H, ptr(out),
-                                          current_stream()), "qbm_qbm_stats_diff")
+    def stats_diff(self, X, labels, mean_c, mean_u, D, H, out, nll=False):
+        """out[theta layout] = statistics(clamped) - statistics(unclamped) of the images given; nll: out holds one more
+        element, the sum of the images' NLL terms (faster_dqbm.py:986-991), from the same launch."""
+        fn = self.lib.qbm_qbm_stats_diff_nll if nll else self.lib.qbm_qbm_stats_diff
+        check(fn(ptr(X), ptr(labels), ptr(mean_c), ptr(mean_u), X.shape[0], D, H, ptr(out), current_stream()),
+              "qbm_qbm_stats_diff_nll" if nll else "qbm_qbm_stats_diff")
         return out
 
     def apply_update(self, theta, diff, D, H, lr, batch):

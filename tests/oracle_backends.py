@@ -72,9 +72,14 @@ class OracleQuboOps:
                                                             seed, offset, chain0 + b * reads)
         return torch.from_numpy(states), torch.from_numpy(mean)
 
-    def stats_diff(self, X, labels, mean_c, mean_u, D, H, out):
+    def stats_diff(self, X, labels, mean_c, mean_u, D, H, out, nll=False):
         d = orc.qbm_stats_diff(_np(X, np.float64), _np(labels, np.int32), _np(mean_c, np.float64), _np(mean_u, np.float64), H)
         out[:d.size] = torch.from_numpy(d)
+        if nll:   # compute_nll's per-image term, summed (src/model/faster_dqbm.py:986-991), in numpy as the reference states it
+            p1 = _np(mean_u, np.float64)[:, 0]
+            probs = np.stack([1.0 - p1, p1], axis=1).astype(np.float32)
+            lp = np.log(probs + np.float32(1e-12))
+            out[d.size] = float(np.sum(-lp[np.arange(len(p1)), _np(labels, np.int64)].astype(np.float64)))
         return out
 
     def apply_update(self, theta, diff, D, H, lr, batch):

@@ -621,6 +621,17 @@ def test_qbm_linear_fields_bitwise(oracle):
         Q = g["Q_clamped"] if labels is not None else g["Q_unclamped"]
         diag = np.stack([np.diag(Q[i]) for i in range(len(X))])
         assert np.max(np.abs(lin.cpu().numpy() - diag)) <= 1e-6 * max(1.0, np.abs(diag).max())  # vs the reference's Q
+    # shapes around the kernel's blocking (64 variables x 4 images per workgroup, chunks of 56 terms through LDS): ragged in
+    # every direction, one chunk, many chunks, the benchmark's; gray-scale pixels and negative weights (no exact products)
+    rs = np.random.RandomState(4)
+    for (B, D, H) in [(1, 1, 1), (3, 55, 63), (4, 56, 64), (5, 57, 65), (9, 113, 130), (73, 784, 256), (2, 300, 257), (6, 8, 700)]:
+        X = rs.random_sample((B, D))
+        Y = rs.randint(0, 2, B)
+        W_vh, W_vo = rs.standard_normal((1 + D, H)) * 0.3, rs.standard_normal(D) * 0.3
+        b_h, b_o = rs.standard_normal(H), np.array([rs.standard_normal()])
+        for labels in (None, Y):
+            lin = q.linear_fields(X, labels, W_vh, W_vo, b_h, b_o, 0.7)
+            assert_bitwise(lin, oracle.qbm_linear_fields(X, labels, W_vh, W_vo, b_h, b_o, 0.7), f"linear fields {B}x{D}x{H}")
 
 
 def test_qbm_batch_stats_bitwise(oracle):
@@ -757,6 +768,12 @@ def test_qbm_device_state_kernels_bitwise(oracle):
         q.stats_diff(t64(X), torch.from_numpy(Y).cuda(), t64(mc), t64(mu), D, H, out)
         want = oracle.qbm_stats_diff(X, Y, mc, mu, H)
         assert np.array_equal(out[:-1].cpu().numpy(), want) and float(out[-1]) == 0.0
+        # ... and with the NLL sum from the same launch (compute_nll's term, faster_dqbm.py:986-991: float32 log, a monitor)
+        out2 = torch.zeros(n_theta + 1, dtype=torch.float64, device="cuda")
+        q.stats_diff(t64(X), torch.from_numpy(Y).cuda(), t64(mc), t64(mu), D, H, out2, nll=True)
+        probs = np.stack([1.0 - mu[:, 0], mu[:, 0]], axis=1).astype(np.float32)
+        nll = float(np.sum(-np.log(probs + np.float32(1e-12))[np.arange(B), Y].astype(np.float64)))
+        assert np.array_equal(out2[:-1].cpu().numpy(), want) and abs(float(out2[-1]) - nll) <= 1e-5 * max(1.0, abs(nll))
         q.apply_update(th, out, D, H, 0.05, float(B))
         assert np.array_equal(th.cpu().numpy(), theta - 0.05 * (want / float(B)))
     # a QUBO without any coefficient: the fallback range
