@@ -110,7 +110,9 @@ __device__ __forceinline__ void row_of_tile(const JR& jr, int t, int p, int lane
     }
 }
 
-// The threshold of a heat-bath update: s_i = 1 iff beta F_i < -logit(u_i)  (== sigma(-beta F_i) > u_i as one compare).
+// The threshold of a heat-bath update: s_i = 1 iff F_i < fl(-logit(u_i) * fl(1 / beta))  (== sigma(-beta F_i) > u_i as ONE compare
+// of the field; until round 4 the field was multiplied by beta at every test -- a vector instruction per flip in a loop that is
+// bound by their number; the rule is this build's own, oracle and kernels state it the same way).
 // -logit(u) = log((1 - u) / u): ONE logarithm of a quotient (round 4; rounds 1-3: log(1 - u) - log(u), two of them -- the
 // thresholds were ~40 % of a sweep's fixed work).  u = 0 gives +inf (the spin is set), u < 1 always.
 __device__ __forceinline__ float neg_logit(float u) { return det_logf((1.0f - u) / u); }
@@ -192,6 +194,7 @@ __device__ __forceinline__ void gibbs_chain(const float* __restrict__ lin, const
     for (int sw = 1; sw <= sweeps; ++sw) {
         float beta = beta1;
         if (sweeps > 1) beta = beta0 * det_expf(lr * ((float)(sw - 1) / (float)(sweeps - 1)));
+        const float ib = 1.0f / beta;   // the thresholds are divided by beta once per sweep, not the fields multiplied at every test
         // Uniforms of this sweep.  Spin i takes word i&3 of Philox block i>>2, so the 64 spins of a tile share 16
         // blocks: one pass in which lane L computes block 64*pass + L serves four tiles, and each spin fetches its word
         // from lane 16*(t&3) + (lane>>2) (ds_bpermute) -- a quarter of the Philox work of one call per spin.
@@ -208,8 +211,8 @@ __device__ __forceinline__ void gibbs_chain(const float* __restrict__ lin, const
             const float w2 = __shfl(ub[t >> 2][2], src, kWave), w3 = __shfl(ub[t >> 2][3], src, kWave);
             const int k = lane & 3;
             const float u = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? w2 : w3;
-            if constexpr (XS && JR::kExactTiles) thr[t] = neg_logit(u);      // whole tiles: every lane holds a spin
-            else thr[t] = (i < nt) ? neg_logit(u) : 0.f;
+            if constexpr (XS && JR::kExactTiles) thr[t] = neg_logit(u) * ib;      // whole tiles: every lane holds a spin
+            else thr[t] = (i < nt) ? neg_logit(u) * ib : 0.f;
         }
         float thrx = 0.f;
         if constexpr (XS) {
@@ -222,7 +225,7 @@ __device__ __forceinline__ void gibbs_chain(const float* __restrict__ lin, const
                 const int e = (n - 1) & 3;
                 thrx_v = neg_logit(e == 0 ? u[0] : e == 1 ? u[1] : e == 2 ? u[2] : u[3]);
             }
-            thrx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(thrx_v), (sw - 1) & 63));
+            thrx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(thrx_v), (sw - 1) & 63)) * ib;
         }
 #pragma unroll
         for (int t = 0; t < NF; ++t) {
@@ -234,7 +237,7 @@ __device__ __forceinline__ void gibbs_chain(const float* __restrict__ lin, const
             const int cnt = all_full ? 64 : min(64, nt - 64 * t);   // <= 0: a tile beyond n (no spin to visit: `pending` is empty)
             unsigned long long pending = (cnt >= 64) ? ~0ull : (cnt <= 0 ? 0ull : ((1ull << cnt) - 1ull));  // spins of this tile not yet visited
             const bool full = all_full || (JR::kExactTiles && t + 1 < NF);
-            unsigned long long want = __ballot((beta * F[t]) < thr[t]) ^ sm[t];
+            unsigned long long want = __ballot(F[t] < thr[t]) ^ sm[t];
             if constexpr (!all_full) want &= pending;
             while (want) {
                 const int l = __builtin_ctzll(want);              // first spin that flips; the ones before it stay
@@ -250,15 +253,15 @@ __device__ __forceinline__ void gibbs_chain(const float* __restrict__ lin, const
                     Fx = Fx + __uint_as_float((uint32_t)__builtin_amdgcn_readlane(__float_as_uint(jx[t]), l) ^ (__float_as_uint(sg) & 0x80000000u));
                 sm[t] ^= 1ull << l;
                 if (all_full || full) {
-                    want = (__ballot((beta * F[t]) < thr[t]) ^ sm[t]) & ((~0ull << l) << 1);   // the spins behind l
+                    want = (__ballot(F[t] < thr[t]) ^ sm[t]) & ((~0ull << l) << 1);   // the spins behind l
                 } else {
                     pending &= (~0ull << l) << 1;
-                    want = (__ballot((beta * F[t]) < thr[t]) ^ sm[t]) & pending;
+                    want = (__ballot(F[t] < thr[t]) ^ sm[t]) & pending;
                 }
             }
         }
         if constexpr (XS) {   // spin n - 1, behind the last tile (every lane holds the same Fx, thrx: a uniform decision)
-            const bool ns = __ballot((beta * Fx) < thrx) != 0ull;
+            const bool ns = __ballot(Fx < thrx) != 0ull;
             if (ns != sx) {
                 const float sg = ns ? 1.0f : -1.0f;
 #pragma unroll
@@ -464,6 +467,7 @@ __global__ __launch_bounds__(64 * kCsrMaxWaves) void k_qubo_gibbs_csr(const floa
         for (int sw = 1; sw <= sweeps; ++sw) {
             float beta = b1;
             if (sweeps > 1) beta = b0 * det_expf(lr * ((float)(sw - 1) / (float)(sweeps - 1)));
+            const float ib = 1.0f / beta;
             // uniforms and thresholds of this sweep: as in gibbs_chain (one Philox pass serves four tiles)
             constexpr int NPASS = (NF + 3) / 4;
             f32x4 ub[NPASS];
@@ -478,7 +482,7 @@ __global__ __launch_bounds__(64 * kCsrMaxWaves) void k_qubo_gibbs_csr(const floa
                 const float w2 = __shfl(ub[t >> 2][2], src, kWave), w3 = __shfl(ub[t >> 2][3], src, kWave);
                 const int k = lane & 3;
                 const float u = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? w2 : w3;
-                thr[t] = (i < n) ? neg_logit(u) : 0.f;
+                thr[t] = (i < n) ? neg_logit(u) * ib : 0.f;
             }
 #pragma unroll
             for (int t = 0; t < NF; ++t) {
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(64 * kCsrMaxWaves) void k_qubo_gibbs_csr(const floa
                 // bits set: 7 % of the launch)
                 const volatile __attribute__((address_space(3))) float* Ft =
                     (const volatile __attribute__((address_space(3))) float*)(Fw + 64 * t + lane);
-                unsigned long long want = (__ballot((beta * *Ft) < thr[t]) ^ sm[t]) & tile;
+                unsigned long long want = (__ballot(*Ft < thr[t]) ^ sm[t]) & tile;
                 // One flip = readlane (where the row's entries lie, how many) -> ds_read_b64 (lane e: entry e) -> ds_add_f32 into
                 // the neighbours' fields -> ds_read_b32 of the tile's fields -> ballot.  What a flip costs on a wavefront that has
                 // its CU to itself is the NUMBER of instructions (each waits for the one before) rather than the two LDS round trips:
@@ -509,7 +513,7 @@ __global__ __launch_bounds__(64 * kCsrMaxWaves) void k_qubo_gibbs_csr(const floa
                         add_row(rowptr[p] + 64, rowptr[p + 1], sgbit);
                     }
                     sm[t] ^= 1ull << l;
-                    want = (__ballot((beta * *Ft) < thr[t]) ^ sm[t]) & tile & ((~0ull << l) << 1);
+                    want = (__ballot(*Ft < thr[t]) ^ sm[t]) & tile & ((~0ull << l) << 1);
                 }
             }
         }

@@ -122,6 +122,21 @@ def main():
                     "ms_per_qubo": round(dt * 1e3 / 146, 3), "chain_sweeps_per_s": round(2 * 73 * 100 * sweeps / dt, 1),
                     "spin_updates_per_s": round(73 * 100 * sweeps * (256 + 257) / dt, 1)})
         print(json.dumps(out[-1]), flush=True)
+    # sample_Q (src/qubo/sampler.py:26-33) on a committed conv-QBM QUBO: the sparse-coupling kernel, one QUBO per host call
+    import os
+
+    from qbm_image_classification_amd.sampler import HipGibbsSampler
+
+    Q = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "cdqbm_qubo.npz"))["Q_unclamped"][0]
+    smp = HipGibbsSampler(num_sweeps=100, seed=7)
+    smp.sample_Q(Q, 100)
+    dt = float("inf")
+    for _ in range(5):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        smp.sample_Q(Q, 100)
+        dt = min(dt, time.perf_counter() - t0)
+    out.append({"what": f"sample_Q conv-QBM QUBO n = {Q.shape[0]}, 100 reads x 100 sweeps, host call ({smp.last_kernel} kernel)", "ms": round(dt * 1e3, 3)})
+    print(json.dumps(out[-1]), flush=True)
 
 
 if __name__ == "__main__":

@@ -65,6 +65,7 @@ timeout -k 10 150 python bench.py --force-dp --no-cpu-baseline > $OUT/${R}_bench
 timeout -k 10 200 python tools/bench_configs.py > $OUT/${R}_other_configs.jsonl 2> gpurun_out/configs.err; echo "configs rc=$?" >> $P
 timeout -k 10 200 python tools/qbm_pipeline.py --time > $OUT/${R}_qbm_pipeline.jsonl 2> gpurun_out/qbm_pipeline.err; echo "qbm rc=$?" >> $P
 timeout -k 10 120 python tools/qubo_bench.py > $OUT/${R}_qubo_bench.jsonl 2> gpurun_out/qubo_bench.err; echo "qubo bench rc=$?" >> $P
+timeout -k 10 120 python tools/qubo_bench.py --conv > $OUT/${R}_qubo_conv.jsonl 2>> gpurun_out/qubo_bench.err; timeout -k 10 120 python tools/qubo_bench.py --conv --dense >> $OUT/${R}_qubo_conv.jsonl 2>> gpurun_out/qubo_bench.err; echo "qubo conv rc=$?" >> $P
 timeout -k 10 300 python tools/bench_train_loop.py 2> gpurun_out/train_loop.err | grep "^{" > $OUT/${R}_train_loop.jsonl; echo "train loop rc=$?" >> $P
 timeout -k 10 100 python tools/disc_step_time.py > $OUT/${R}_disc_step.jsonl 2> gpurun_out/disc_step.err; echo "disc step rc=$?" >> $P
 cat $P; head -c 600 $OUT/${R}_bench.json
