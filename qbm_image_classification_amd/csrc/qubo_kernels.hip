@@ -62,6 +62,8 @@ struct JTri {
             // (+ the triangle's LDS address: every read below adds ci -- or `up`, which is some lane's ci -- exactly once, so the
             // address needs no further add; `tri + offset` cost one v_add_u32 per flip for a base the linker resolves to 0)
             ci[tt] = 4 * (i * n - (i * (i - 1)) / 2 - i) + (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)tri;
+            asm volatile("" : "+v"(ci[tt]));   // (opaque: the compiler otherwise keeps the offset unscaled and rebuilds (x + p) << 2
+                                               // in the flip loop: two vector instructions for one add)
         }
     }
     template <int T, int NF>
@@ -81,7 +83,10 @@ struct JTri {
         for (int tt = 0; tt < NF; ++tt) {
             int ad;
             if (tt < T) ad = ci[tt] + p4;                // every spin of an earlier tile is below p
-            else if (tt > T) ad = rb + 256 * tt;         // every spin of a later tile is above p
+            // every spin of a later tile is above p.  (After a flip in tile 0 the compiler pairs the reads of tiles 1 and 2 and moves
+            // both halves to where the packed updates of (0,1), (2,3) take them; addressing tile 1 through its own index register --
+            // one v_add for two v_mov -- was 0.6 % SLOWER in alternating runs: left as it is.)
+            else if (tt > T) ad = rb + 256 * tt;
             else ad = min(up + ic[tt], ci[tt] + p4);     // the spin's own tile: T(min(i, p), max(i, p)) is the SMALLER of the two
                                                          // candidates (S(r) - r grows by n - 1 - r >= 1 words per row, a column
                                                          // by one): a v_min instead of a compare and a select
