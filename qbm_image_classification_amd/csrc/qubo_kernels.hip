@@ -653,6 +653,25 @@ __global__ __launch_bounds__(64 * kLfIm) void k_linear_fields(const double* __re
             if (c + kLfAhead - 1 < nc) fetch((u + kLfAhead - 1) % kLfAhead, (c + kLfAhead - 1) * kLfKC);
             const int kmax = min(kLfKC, D - c * kLfKC);
             int kk = 0;
+            if (kmax == kLfKC) {
+                // a whole chunk: the operands of the NEXT 8 terms are read from LDS while the current 8 are added (the sum is a
+                // chain of dependent adds: nothing but that chain should be waited for)
+                double xv[8], wv[8], xn[8], wn[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { xv[q] = xbuf[cur][w][q]; wv[q] = wbuf[cur][q][lane]; }
+#pragma unroll
+                for (int g8 = 0; g8 < kLfKC / 8; ++g8) {
+                    if (g8 + 1 < kLfKC / 8) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) { xn[q] = xbuf[cur][w][8 * g8 + 8 + q]; wn[q] = wbuf[cur][8 * g8 + 8 + q][lane]; }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a += xv[q] * wv[q];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { xv[q] = xn[q]; wv[q] = wn[q]; }
+                }
+                kk = kLfKC;
+            }
             for (; kk + 8 <= kmax; kk += 8) {
                 double xv[8], wv[8];
 #pragma unroll
@@ -817,7 +836,24 @@ __global__ __launch_bounds__(256) void k_qbm_stats_diff(const double* __restrict
     if (idx < nW) {
         const int k = (int)(idx / H), j = (int)(idx % H);
         if (k < D) {
-            for (int i = 0; i < B; ++i) {
+            // (the operands of 8 images requested together: the sums are two chains of B dependent float64 operations, the
+            // loads do not depend on them)
+            int i = 0;
+            for (; i + 8 <= B; i += 8) {
+                double x[8], mc[8], mu[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    x[q] = X[(long)(i + q) * D + k];
+                    mc[q] = mean_c[(long)(i + q) * H + j];
+                    mu[q] = mean_u[(long)(i + q) * nu + 1 + j];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    c += x[q] * mc[q];
+                    u += x[q] * mu[q];
+                }
+            }
+            for (; i < B; ++i) {
                 const double x = X[(long)i * D + k];
                 c += x * mean_c[(long)i * H + j];
                 u += x * mean_u[(long)i * nu + 1 + j];
