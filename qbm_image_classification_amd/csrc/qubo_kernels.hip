@@ -533,10 +533,11 @@ __global__ __launch_bounds__(64 * kCsrMaxWaves) void k_qubo_gibbs_csr(const floa
 // mean over reads, float64: exact count / R  (np.average(np_samples, axis=0) on {0,1} samples,
 // src/model/faster_dqbm.py:780)
 __global__ __launch_bounds__(256) void k_read_mean(const uint8_t* __restrict__ states, double* __restrict__ mean,
-                                                   int B, int R, int n)
+                                                   int B, int R, int n, const int* __restrict__ skip /* NULL, or a status word: != 0 -> nothing is written */)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * n) return;
+    if (skip && *skip != 0) return;   // (the sparse sampler gave up: its states are not there, the means stay untouched too)
     const int b = idx / n, i = idx % n;
     int cnt = 0;   // (an integer count: any order; 10 reads requested together instead of one round trip per read)
     const uint8_t* s = states + (long)b * R * n + i;
@@ -1023,7 +1024,7 @@ int qbm_qubo_gibbs_dev(const float* lin, const float* J, int B, int R, int n, in
     }
     if (rc) return rc;
     if (mean) {
-        hipLaunchKernelGGL(k_read_mean, dim3((B * n + 255) / 256), dim3(256), 0, st, states, mean, B, R, n);
+        hipLaunchKernelGGL(k_read_mean, dim3((B * n + 255) / 256), dim3(256), 0, st, states, mean, B, R, n, (const int*)nullptr);
         QBM_CHECK_LAUNCH("k_read_mean");
     }
     return QBM_OK;
@@ -1082,7 +1083,7 @@ int qbm_qubo_gibbs_csr(const float* lin, const void* workspace, long cap, int B,
     }
     if (rc) return rc;
     if (mean) {
-        hipLaunchKernelGGL(k_read_mean, dim3((B * n + 255) / 256), dim3(256), 0, st, states, mean, B, R, n);
+        hipLaunchKernelGGL(k_read_mean, dim3((B * n + 255) / 256), dim3(256), 0, st, states, mean, B, R, n, (const int*)ws);   // (ws[0]: the status word)
         QBM_CHECK_LAUNCH("k_read_mean");
     }
     return QBM_OK;
