@@ -120,7 +120,29 @@ __device__ __forceinline__ void row_of_tile(const JR& jr, int t, int p, int lane
 // bound by their number; the rule is this build's own, oracle and kernels state it the same way).
 // -logit(u) = log((1 - u) / u): ONE logarithm of a quotient (round 4; rounds 1-3: log(1 - u) - log(u), two of them -- the
 // thresholds were ~40 % of a sweep's fixed work).  u = 0 gives +inf (the spin is set), u < 1 always.
-__device__ __forceinline__ float neg_logit(float u) { return det_logf((1.0f - u) / u); }
+// The logarithm is the sampler's own (round 4): exponent + a degree-7 polynomial of log(1 + t) / t on [sqrt(1/2) - 1, sqrt(2) - 1]
+// (absolute error 7e-8 -- a spin's probability moves by 2e-8), a fixed sequence of fp32 operations without the division,
+// the range tests and the special cases of det_logf: 29 vector instructions per threshold instead of 58, four thresholds per
+// lane and sweep (a sixth of a sweep's instructions at n = 256).  oracle/qbm_oracle.c states the same sequence.
+__device__ __forceinline__ float neg_logit(float u)
+{
+    const float q = (1.0f - u) / u;   // in [2^-24, 2^24]: normal;  u = 0 -> +inf, selected below
+    uint32_t ix = __float_as_uint(q);
+    ix += 0x3f800000u - 0x3f3504f3u;
+    const int k = (int)(ix >> 23) - 0x7f;
+    ix = (ix & 0x007fffffu) + 0x3f3504f3u;
+    const float t = __uint_as_float(ix) - 1.0f;
+    float p = -0.0991365612f;
+    p = __builtin_fmaf(p, t, 0.163385555f);
+    p = __builtin_fmaf(p, t, -0.173631534f);
+    p = __builtin_fmaf(p, t, 0.198853612f);
+    p = __builtin_fmaf(p, t, -0.249577805f);
+    p = __builtin_fmaf(p, t, 0.333356887f);
+    p = __builtin_fmaf(p, t, -0.500006974f);
+    p = __builtin_fmaf(p, t, 0.999999821f);
+    const float v = __builtin_fmaf((float)k, 0.693147182f, t * p);
+    return (u == 0.0f) ? __builtin_inff() : v;
+}
 
 // One chain (image b, read r) on one wavefront.
 // XS ("extra spin", n = 64 NF + 1: the unclamped QUBO of a Disc_QBM with 64 k hidden nodes -- 257 variables at 256): the LAST
