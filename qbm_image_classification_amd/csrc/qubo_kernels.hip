@@ -174,25 +174,37 @@ __device__ __forceinline__ void gibbs_chain(const float* __restrict__ lin, const
     float jx[NF], Fx = 0.f;                       // XS: J[n-1, tile spins], the extra spin's field (the same in every lane)
     bool sx = false;
 
+    // Which uniform a spin takes (the sampler's own layout, round 4): spin i = 64 t + l reads word t & 3 of Philox block
+    // 64 (t >> 2) + l of the draw id -- Philox column gibbs_col(i) = 256 (t >> 2) + 4 l + (t & 3).  One Philox call of lane l
+    // (block 64 pass + l) then IS the uniforms of its spins in four tiles: no exchange between lanes.  (Rounds 1-3 gave spin i
+    // column i, as the RBM's draws do: a tile's 64 spins shared 16 blocks, and every sweep fetched each spin's word from
+    // another lane -- four ds_bpermute and three selects per tile.)
+    constexpr int NPASS = (NF + 3) / 4;
+    // the extra spin n - 1 = 64 NF (XS): tile NF, lane 0
+    constexpr uint32_t kXsBlock = 64u * (uint32_t)(NF >> 2);
+    constexpr int kXsWord = NF & 3;
     // start state s_i = (u < 0.5), draw id `offset`
+    {
+        f32x4 u0[NPASS];
 #pragma unroll
-    for (int t = 0; t < NF; ++t) {
-        const int i = 64 * t + lane;
-        bool s0 = false;
-        F[t] = 0.f;
-        jx[t] = 0.f;
-        if (i < nt) {
-            const f32x4 u = uniform4(seed, offset, row, (uint32_t)(i >> 2));
-            s0 = u[i & 3] < 0.5f;
-            F[t] = lin[(long)b * n + i];
-            if constexpr (XS) jx[t] = Jx[i];
+        for (int ps = 0; ps < NPASS; ++ps) u0[ps] = uniform4(seed, offset, row, (uint32_t)(64 * ps + lane));
+#pragma unroll
+        for (int t = 0; t < NF; ++t) {
+            const int i = 64 * t + lane;
+            bool s0 = false;
+            F[t] = 0.f;
+            jx[t] = 0.f;
+            if (i < nt) {
+                s0 = u0[t >> 2][t & 3] < 0.5f;
+                F[t] = lin[(long)b * n + i];
+                if constexpr (XS) jx[t] = Jx[i];
+            }
+            sm[t] = __ballot(s0);
         }
-        sm[t] = __ballot(s0);
     }
     if constexpr (XS) {
-        const f32x4 u = uniform4(seed, offset, row, (uint32_t)((n - 1) >> 2));
-        const int e = (n - 1) & 3;
-        sx = (e == 0 ? u[0] : e == 1 ? u[1] : e == 2 ? u[2] : u[3]) < 0.5f;
+        const f32x4 u = uniform4(seed, offset, row, kXsBlock);
+        sx = u[kXsWord] < 0.5f;
         Fx = lin[(long)b * n + n - 1];
     }
     // initial fields: + J[j, :] for set spins j ascending
@@ -222,10 +234,7 @@ __device__ __forceinline__ void gibbs_chain(const float* __restrict__ lin, const
         float beta = beta1;
         if (sweeps > 1) beta = beta0 * det_expf(lr * ((float)(sw - 1) / (float)(sweeps - 1)));
         const float ib = 1.0f / beta;   // the thresholds are divided by beta once per sweep, not the fields multiplied at every test
-        // Uniforms of this sweep.  Spin i takes word i&3 of Philox block i>>2, so the 64 spins of a tile share 16
-        // blocks: one pass in which lane L computes block 64*pass + L serves four tiles, and each spin fetches its word
-        // from lane 16*(t&3) + (lane>>2) (ds_bpermute) -- a quarter of the Philox work of one call per spin.
-        constexpr int NPASS = (NF + 3) / 4;
+        // Uniforms of this sweep: one Philox call per lane and four tiles (the layout above)
         f32x4 ub[NPASS];
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps)
@@ -233,24 +242,19 @@ __device__ __forceinline__ void gibbs_chain(const float* __restrict__ lin, const
 #pragma unroll
         for (int t = 0; t < NF; ++t) {
             const int i = 64 * t + lane;
-            const int src = 16 * (t & 3) + (lane >> 2);
-            const float w0 = __shfl(ub[t >> 2][0], src, kWave), w1 = __shfl(ub[t >> 2][1], src, kWave);
-            const float w2 = __shfl(ub[t >> 2][2], src, kWave), w3 = __shfl(ub[t >> 2][3], src, kWave);
-            const int k = lane & 3;
-            const float u = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? w2 : w3;
+            const float u = ub[t >> 2][t & 3];
             if constexpr (XS && JR::kExactTiles) thr[t] = neg_logit(u) * ib;      // whole tiles: every lane holds a spin
             else thr[t] = (i < nt) ? neg_logit(u) * ib : 0.f;
         }
         float thrx = 0.f;
         if constexpr (XS) {
-            // The extra spin's uniform (word (n-1)&3 of block (n-1)>>2 of the sweep's draw id) is one number per sweep: lane L
+            // The extra spin's uniform (word kXsWord of block kXsBlock of the sweep's draw id) is one number per sweep: lane L
             // evaluates Philox and the threshold for sweep sw + L, once every 64 sweeps -- per sweep that leaves one v_readlane
             // (a whole Philox call and a logarithm per sweep for ONE spin were a twentieth of the launch).  Same counters, same
             // function of them: the same thresholds.
             if (((sw - 1) & 63) == 0) {
-                const f32x4 u = uniform4(seed, offset + (uint64_t)sw + (uint64_t)lane, row, (uint32_t)((n - 1) >> 2));
-                const int e = (n - 1) & 3;
-                thrx_v = neg_logit(e == 0 ? u[0] : e == 1 ? u[1] : e == 2 ? u[2] : u[3]);
+                const f32x4 u = uniform4(seed, offset + (uint64_t)sw + (uint64_t)lane, row, kXsBlock);
+                thrx_v = neg_logit(u[kXsWord]);
             }
             thrx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(thrx_v), (sw - 1) & 63)) * ib;
         }
@@ -466,19 +470,25 @@ __global__ __launch_bounds__(64 * kCsrMaxWaves) void k_qubo_gibbs_csr(const floa
         const uint32_t row = chain0 + (uint32_t)ch;
         float thr[NF];
         unsigned long long sm[NF];
-        // start state s_i = (u < 0.5), draw id `offset`;  F = lin
+        // start state s_i = (u < 0.5), draw id `offset` (the draw layout of gibbs_chain: lane l's Philox block 64 pass + l holds the
+        // uniforms of its spins in four tiles);  F = lin
+        constexpr int NPASS = (NF + 3) / 4;
+        {
+            f32x4 u0[NPASS];
 #pragma unroll
-        for (int t = 0; t < NF; ++t) {
-            const int i = 64 * t + lane;
-            bool s0 = false;
-            float f0 = 0.f;
-            if (i < n) {
-                const f32x4 u = uniform4(seed, offset, row, (uint32_t)(i >> 2));
-                s0 = u[i & 3] < 0.5f;
-                f0 = lin[(long)b * n + i];
+            for (int ps = 0; ps < NPASS; ++ps) u0[ps] = uniform4(seed, offset, row, (uint32_t)(64 * ps + lane));
+#pragma unroll
+            for (int t = 0; t < NF; ++t) {
+                const int i = 64 * t + lane;
+                bool s0 = false;
+                float f0 = 0.f;
+                if (i < n) {
+                    s0 = u0[t >> 2][t & 3] < 0.5f;
+                    f0 = lin[(long)b * n + i];
+                }
+                Fw[i] = f0;
+                sm[t] = __ballot(s0);
             }
-            Fw[i] = f0;
-            sm[t] = __ballot(s0);
         }
         // initial fields: + J[j, :] for set spins j ascending
 #pragma unroll
@@ -495,8 +505,7 @@ __global__ __launch_bounds__(64 * kCsrMaxWaves) void k_qubo_gibbs_csr(const floa
             float beta = b1;
             if (sweeps > 1) beta = b0 * det_expf(lr * ((float)(sw - 1) / (float)(sweeps - 1)));
             const float ib = 1.0f / beta;
-            // uniforms and thresholds of this sweep: as in gibbs_chain (one Philox pass serves four tiles)
-            constexpr int NPASS = (NF + 3) / 4;
+            // uniforms and thresholds of this sweep: as in gibbs_chain (one Philox call per lane and four tiles)
             f32x4 ub[NPASS];
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps)
@@ -504,12 +513,7 @@ __global__ __launch_bounds__(64 * kCsrMaxWaves) void k_qubo_gibbs_csr(const floa
 #pragma unroll
             for (int t = 0; t < NF; ++t) {
                 const int i = 64 * t + lane;
-                const int src = 16 * (t & 3) + (lane >> 2);
-                const float w0 = __shfl(ub[t >> 2][0], src, kWave), w1 = __shfl(ub[t >> 2][1], src, kWave);
-                const float w2 = __shfl(ub[t >> 2][2], src, kWave), w3 = __shfl(ub[t >> 2][3], src, kWave);
-                const int k = lane & 3;
-                const float u = k == 0 ? w0 : k == 1 ? w1 : k == 2 ? w2 : w3;
-                thr[t] = (i < n) ? neg_logit(u) * ib : 0.f;
+                thr[t] = (i < n) ? neg_logit(ub[t >> 2][t & 3]) * ib : 0.f;
             }
 #pragma unroll
             for (int t = 0; t < NF; ++t) {

@@ -402,7 +402,8 @@ class Disc_QBM:
 
     def _step_device(self, X, labels, learning_rate):
         """One training iteration with every array on the device (src/model/faster_dqbm.py:998-1064):
-        -> (error of the output bias, average NLL) as 0-dim float64 device tensors.  With a data-parallel group every rank
+        -> (sum of the output bias' error, sum of the NLL terms) as 0-dim float64 device tensors and the batch size they are to be
+        divided by (on the host).  With a data-parallel group every rank
         is handed the SAME minibatch, samples only its rows, and the statistics difference plus the NLL sum meet in ONE
         float64 all-reduce; every replica then applies the same update."""
         import torch
@@ -425,13 +426,15 @@ class Disc_QBM:
         self._dev_newer = True
         self._J_cache.pop(False, None)                                            # the label row of W_vh has moved
         # W_oo (empty triu for one output node) and W_hh statistics are identically zero in the reference (Q8)
-        return buf[-2] / B, buf[-1] / B
+        # (the SUMS: their division by the batch size is the host's -- a float64 division by torch on the device is not correctly
+        # rounded, and the error of the output bias is compared with the reference's numpy value bit for bit)
+        return buf[-2], buf[-1], float(B)
 
     def train_for_one_iteration(self, x_batch, y_batch, learning_rate, nll=None):
         """src/model/faster_dqbm.py:998-1064 -> (errors_biases_output, avg_batch_nll)"""
         X, labels = self._to_dev(x_batch, y_batch)
-        err_bo, avg_nll = self._step_device(X, labels, learning_rate)
-        err_bo, avg_batch_loss = np.array([float(err_bo)]), float(avg_nll)
+        err_sum, nll_sum, Bf = self._step_device(X, labels, learning_rate)
+        err_bo, avg_batch_loss = np.array([float(err_sum) / Bf]), float(nll_sum) / Bf
         self.training_history.nll_per_batch.append(avg_batch_loss)
         return err_bo, avg_batch_loss
 
@@ -489,12 +492,12 @@ class Disc_QBM:
         for epoch in range(1, self.epochs + 1):
             batchnum = 1
             num_batches = max(1, n_train // batch_size)
-            errs, nlls = [], []
+            errs, nlls, bsz = [], [], []
             import torch
 
             def flush():   # the epoch's ONE synchronisation: per-batch error / NLL to the host (what has been enqueued so far)
-                e = torch.stack(errs).cpu().tolist() if errs else []
-                n = torch.stack(nlls).cpu().tolist() if nlls else []
+                e = [v / bf for v, bf in zip(torch.stack(errs).cpu().tolist(), bsz)] if errs else []
+                n = [v / bf for v, bf in zip(torch.stack(nlls).cpu().tolist(), bsz)] if nlls else []
                 return e, n
 
             try:
@@ -502,9 +505,10 @@ class Disc_QBM:
                     xb, yb = Xd[b:b + batch_size], Yd[b:b + batch_size]       # the last partial batch is kept (:1106-1111)
                     if xb.shape[0] == 0:
                         continue
-                    err_bo, avg_nll = self._step_device(xb, yb, learning_rate)
-                    errs.append(err_bo)
-                    nlls.append(avg_nll)
+                    err_sum, nll_sum, Bf = self._step_device(xb, yb, learning_rate)
+                    errs.append(err_sum)
+                    nlls.append(nll_sum)
+                    bsz.append(Bf)
                     batchnum += 1
                 errs_h, nlls_h = flush()      # inside the try: an asynchronous device failure surfaces HERE
             except Exception:

@@ -812,7 +812,8 @@ def test_disc_qbm_device_step_equals_oracle_double(oracle):
     for it in range(3):
         eg, ng = g.train_for_one_iteration(X, Y, 0.05)
         eo, no = o.train_for_one_iteration(X, Y, 0.05)
-        assert np.array_equal(eg, eo) and abs(ng - no) <= 1e-6, it
+        # (the NLL is a sum of float32 logarithms, of 1e-12 when an output mean is 0 or 1: one ulp of such a term is 1.9e-6)
+        assert np.array_equal(eg, eo) and abs(ng - no) <= 1e-5, (it, ng, no)
         for name in ("weights_all_visible_to_hidden", "weights_clamped_visible_to_output", "biases_hidden", "biases_output"):
             assert np.array_equal(getattr(g, name), getattr(o, name)), (it, name)
     assert np.array_equal(g.weights_hidden_hidden, o.weights_hidden_hidden)       # Q8: never learns
