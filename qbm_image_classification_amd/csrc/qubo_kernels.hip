@@ -230,10 +230,18 @@ __device__ __forceinline__ void gibbs_chain(const float* __restrict__ lin, const
 
     const float lr = (sweeps > 1) ? det_logf(beta1 / beta0) : 0.f;  // geometric schedule exponent
     float thrx_v = 0.f;   // XS: the extra spin's thresholds of 64 sweeps, one per lane
+    float ibv = 0.f;      // 1 / beta of 64 sweeps, one per lane
     for (int sw = 1; sw <= sweeps; ++sw) {
-        float beta = beta1;
-        if (sweeps > 1) beta = beta0 * det_expf(lr * ((float)(sw - 1) / (float)(sweeps - 1)));
-        const float ib = 1.0f / beta;   // the thresholds are divided by beta once per sweep, not the fields multiplied at every test
+        // 1 / beta of the sweep (the thresholds are divided by beta once per sweep, not the fields multiplied at every test).  The
+        // schedule is the same number in every lane: lane L evaluates it for sweep sw + L, once every 64 sweeps (an exponential
+        // and two divisions per sweep were 3 % of a sweep's instructions); per sweep that leaves one v_readlane.
+        if (((sw - 1) & 63) == 0) {
+            const int s2 = sw + lane;
+            float bt = beta1;
+            if (sweeps > 1) bt = beta0 * det_expf(lr * ((float)(s2 - 1) / (float)(sweeps - 1)));
+            ibv = 1.0f / bt;
+        }
+        const float ib = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ibv), (sw - 1) & 63));
         // Uniforms of this sweep: one Philox call per lane and four tiles (the layout above)
         f32x4 ub[NPASS];
 #pragma unroll
@@ -501,10 +509,15 @@ __global__ __launch_bounds__(64 * kCsrMaxWaves) void k_qubo_gibbs_csr(const floa
             }
         }
         const float lr = (sweeps > 1) ? det_logf(b1 / b0) : 0.f;
+        float ibv = 0.f;
         for (int sw = 1; sw <= sweeps; ++sw) {
-            float beta = b1;
-            if (sweeps > 1) beta = b0 * det_expf(lr * ((float)(sw - 1) / (float)(sweeps - 1)));
-            const float ib = 1.0f / beta;
+            if (((sw - 1) & 63) == 0) {   // (as in gibbs_chain: lane L holds 1 / beta of sweep sw + L)
+                const int s2 = sw + lane;
+                float bt = b1;
+                if (sweeps > 1) bt = b0 * det_expf(lr * ((float)(s2 - 1) / (float)(sweeps - 1)));
+                ibv = 1.0f / bt;
+            }
+            const float ib = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ibv), (sw - 1) & 63));
             // uniforms and thresholds of this sweep: as in gibbs_chain (one Philox call per lane and four tiles)
             f32x4 ub[NPASS];
 #pragma unroll
