@@ -379,7 +379,7 @@ QBM_API int qbm_qubo_from_Q(const void* Q, int q_is_f64, int n, float* lin, floa
 
 /* ---- sparse couplings: the rows of J as CSR entries in LDS (round 4) --------------------------------
  * For QUBOs whose triangle does not fit a CU's LDS (n > 276) but whose NON-ZERO couplings do: the conv-QBM QUBOs behind
- * sample_Q (src/qubo/sampler.py:26-33; n = 717 with 5762 non-zero entries of 514 089).  Same chain, same draws, same
+ * sample_Q (src/qubo/sampler.py:26-33; n = 717: 10 092 non-zero couplings of 513 372).  Same chain, same draws, same
  * states bit for bit as qbm_qubo_gibbs_dev on the same (lin, J): only where a flip finds its row differs.
  *   cap = qbm_qubo_csr_max_entries(n, B * R)      entries the LDS holds beside the chains' fields (0: bad arguments)
  *   ws  = qbm_qubo_csr_workspace_bytes(n, cap)    device bytes, 8-byte aligned

@@ -369,8 +369,8 @@ __global__ __launch_bounds__(64 * kGibbsLdsWaves) void k_qubo_gibbs_lds(const fl
 
 // ---------------------------------------------------------------------------------------------
 // Sparse couplings (round 4): a QUBO whose triangle does not fit the LDS (n > 276) but whose NON-ZERO couplings do -- the
-// conv-QBM QUBOs of src/qubo/sampler.py's sample_Q protocol: n = 717, 5762 non-zero entries of 514 089, every row of J a
-// 2.9 KB read from L2 of which 8 words matter.  The rows live in LDS as CSR entries {byte offset of the column, value}; the
+// conv-QBM QUBOs of src/qubo/sampler.py's sample_Q protocol: n = 717, 10 092 non-zero couplings of 513 372, every row of J a
+// 2.9 KB read from L2 of which 16 words matter.  The rows live in LDS as CSR entries {byte offset of the column, value}; the
 // chain's FIELDS live in LDS as well (n floats per wavefront), because a flip now touches the fields of the row's few
 // neighbours, whichever lanes would hold them: one ds_read_b64 of the row's entries (lane e takes entry e) and one
 // ds_add_f32 into F[column] -- no return value, different addresses within a row, and the LDS executes a wavefront's

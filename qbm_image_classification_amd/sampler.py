@@ -222,7 +222,7 @@ class HipGibbsSampler:
                                                      self.seed, self._calls << 20, 0, ptr(b["states"]), None, st), "qbm_qubo_gibbs_dev")
         sparse = b["csr"] is not None and self.sparse
         if sparse:
-            # too wide for the LDS triangle: the non-zero couplings as CSR rows in LDS (a conv-QBM QUBO holds 1 % of them) -- the
+            # too wide for the LDS triangle: the non-zero couplings as CSR rows in LDS (a conv-QBM QUBO holds 2 % of them) -- the
             # same states bit for bit, at a fraction of a flip's cost.  Whether they fit is known on the device only: the status
             # word comes back with the samples, and a matrix that does not fit is sampled again by the dense kernel below.
             check(lib.qbm_qubo_csr_build(ptr(b["J"]), n, b["cap"], ptr(b["csr"]), st), "qbm_qubo_csr_build")
