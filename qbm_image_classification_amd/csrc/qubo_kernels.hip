@@ -733,6 +733,32 @@ __global__ __launch_bounds__(64 * kLfIm) void k_linear_fields(const double* __re
 // ---------------------------------------------------------------------------------------------
 __host__ __device__ inline long qbm_theta_len(int D, int H) { return (long)(1 + D) * H + D + H + 1; }
 
+// sum_b |J_ab| (ascending b, float64) and the smallest non-zero |J_ab| of one row, from its magnitudes in LDS: ONE thread (the
+// sum's order is the contract).  Eight magnitudes are read together in front of their eight adds.  (Not what bounds these
+// launches: k_qubo_from_Q's 50 us at n = 717 are its column reads Q[b, a], one cache line per element.)
+__device__ __forceinline__ void row_stats(const float* mag /* LDS, 16-byte aligned */, int n, double* rowabs, double* rowmin)
+{
+    double sum = 0.0, mn = 0.0;
+    int b = 0;
+    for (; b + 8 <= n; b += 8) {
+        const float4 m0 = *reinterpret_cast<const float4*>(mag + b), m1 = *reinterpret_cast<const float4*>(mag + b + 4);
+        const float m[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const double av = (double)m[q];
+            sum += av;
+            if (av > 0.0 && (mn == 0.0 || av < mn)) mn = av;
+        }
+    }
+    for (; b < n; ++b) {
+        const double av = (double)mag[b];
+        sum += av;
+        if (av > 0.0 && (mn == 0.0 || av < mn)) mn = av;
+    }
+    *rowabs = sum;
+    *rowmin = mn;
+}
+
 // Image-independent couplings of the QUBO (create_qubo_matrix_from, :242-243 clamped, :256-271 unclamped) as the sampler
 // wants them: symmetric fp32 J with zero diagonal, J_ab = fp32(Q_ab / beta_eff) of the upper-triangular Q.  One wavefront
 // per row: the lanes write the row's entries, lane 0 then adds their magnitudes in ascending column order (float64) for
@@ -742,7 +768,7 @@ __global__ __launch_bounds__(64) void k_qbm_couplings(const double* __restrict__
                                                       int H, int clamped, double beta_eff, float* __restrict__ J,
                                                       double* __restrict__ rowabs, double* __restrict__ rowmin)
 {
-    __shared__ float mag[QBM_MAX_QUBO_VARS];
+    __shared__ __attribute__((aligned(16))) float mag[QBM_MAX_QUBO_VARS];
     const int n = clamped ? H : H + 1, o = clamped ? 0 : 1;
     const int a = blockIdx.x, lane = threadIdx.x;
     for (int b = lane; b < n; b += 64) {
@@ -759,14 +785,7 @@ __global__ __launch_bounds__(64) void k_qbm_couplings(const double* __restrict__
     }
     __syncthreads();
     if (lane != 0) return;
-    double sum = 0.0, mn = 0.0;
-    for (int b = 0; b < n; ++b) {
-        const double av = (double)mag[b];
-        sum += av;
-        if (av > 0.0 && (mn == 0.0 || av < mn)) mn = av;
-    }
-    rowabs[a] = sum;
-    rowmin[a] = mn;
+    row_stats(mag, n, rowabs + a, rowmin + a);
 }
 
 // sample_Q's host side on the device (src/qubo/sampler.py:26-33 hands over ONE n x n QUBO per call): from the matrix as the
@@ -779,7 +798,7 @@ template <class TQ>
 __global__ __launch_bounds__(64) void k_qubo_from_Q(const TQ* __restrict__ Q, int n, float* __restrict__ lin, float* __restrict__ J,
                                                     double* __restrict__ rowabs, double* __restrict__ rowmin, int* __restrict__ any_off)
 {
-    __shared__ float mag[QBM_MAX_QUBO_VARS];
+    __shared__ __attribute__((aligned(16))) float mag[QBM_MAX_QUBO_VARS];
     const int a = blockIdx.x, lane = threadIdx.x;
     bool nz = false;
     for (int b = lane; b < n; b += 64) {
@@ -797,14 +816,7 @@ __global__ __launch_bounds__(64) void k_qubo_from_Q(const TQ* __restrict__ Q, in
     if (__ballot(nz) != 0ull && lane == 0) atomicOr(any_off, 1);
     __syncthreads();
     if (lane != 0) return;
-    double sum = 0.0, mn = 0.0;
-    for (int b = 0; b < n; ++b) {
-        const double av = (double)mag[b];
-        sum += av;
-        if (av > 0.0 && (mn == 0.0 || av < mn)) mn = av;
-    }
-    rowabs[a] = sum;
-    rowmin[a] = mn;
+    row_stats(mag, n, rowabs + a, rowmin + a);
 }
 
 // uint8 {0,1} states -> float32 (sample_Q returns float32[num_reads, n], src/qubo/sampler.py:33)
