@@ -735,7 +735,7 @@ __host__ __device__ inline long qbm_theta_len(int D, int H) { return (long)(1 + 
 
 // sum_b |J_ab| (ascending b, float64) and the smallest non-zero |J_ab| of one row, from its magnitudes in LDS: ONE thread (the
 // sum's order is the contract).  Eight magnitudes are read together in front of their eight adds.  (Not what bounds these
-// launches: k_qubo_from_Q's 50 us at n = 717 are its column reads Q[b, a], one cache line per element.)
+// launches.)
 __device__ __forceinline__ void row_stats(const float* mag /* LDS, 16-byte aligned */, int n, double* rowabs, double* rowmin)
 {
     double sum = 0.0, mn = 0.0;
@@ -793,27 +793,43 @@ __global__ __launch_bounds__(64) void k_qbm_couplings(const double* __restrict__
 // operands in one launch:  lin_i = fp32(Q_ii);  J_ab = fp32(Q_ab + Q_ba) for a != b (the sum in the matrix's own precision, like
 // numpy's (off + off.T).astype(float32));  rowabs / rowmin as k_qbm_couplings delivers them (ascending column order, float64);
 // any_off[0] = 1 if some off-diagonal entry is non-zero (the reference short-circuits a QUBO without quadratic terms).
-// One wavefront per row.
+// (round 4: in 64 x 64 tiles through LDS -- a wavefront per row read the column Q[b, a] one cache line per element: 50 us at
+// n = 717 -- and the row statistics from the finished J in a second launch)
 template <class TQ>
-__global__ __launch_bounds__(64) void k_qubo_from_Q(const TQ* __restrict__ Q, int n, float* __restrict__ lin, float* __restrict__ J,
-                                                    double* __restrict__ rowabs, double* __restrict__ rowmin, int* __restrict__ any_off)
+__global__ __launch_bounds__(256) void k_qubo_from_Q(const TQ* __restrict__ Q, int n, float* __restrict__ lin, float* __restrict__ J,
+                                                     int* __restrict__ any_off)
+{
+    __shared__ TQ tA[64][65], tB[64][65];   // Q[a0 + r, b0 + c] and Q[b0 + r, a0 + c]
+    const int a0 = 64 * (int)blockIdx.y, b0 = 64 * (int)blockIdx.x;
+    const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int r = w; r < 64; r += 4) {
+        tA[r][c] = (a0 + r < n && b0 + c < n) ? Q[(long)(a0 + r) * n + b0 + c] : (TQ)0;
+        tB[r][c] = (b0 + r < n && a0 + c < n) ? Q[(long)(b0 + r) * n + a0 + c] : (TQ)0;
+    }
+    __syncthreads();
+    bool nz = false;
+    for (int r = w; r < 64; r += 4) {
+        const int a = a0 + r, b = b0 + c;
+        if (a >= n || b >= n) continue;
+        const TQ qab = tA[r][c];
+        float v = 0.f;
+        if (a != b) {
+            v = (float)(qab + tB[c][r]);
+            nz = nz || (qab != (TQ)0);        // numpy's (Q - diag(diag(Q))).any()
+        } else {
+            lin[a] = (float)qab;
+        }
+        J[(long)a * n + b] = v;
+    }
+    if (__ballot(nz) != 0ull && (threadIdx.x & 63) == 0) atomicOr(any_off, 1);
+}
+
+// rowabs / rowmin of a finished J (one wavefront per row)
+__global__ __launch_bounds__(64) void k_qubo_row_stats(const float* __restrict__ J, int n, double* __restrict__ rowabs, double* __restrict__ rowmin)
 {
     __shared__ __attribute__((aligned(16))) float mag[QBM_MAX_QUBO_VARS];
     const int a = blockIdx.x, lane = threadIdx.x;
-    bool nz = false;
-    for (int b = lane; b < n; b += 64) {
-        float v = 0.f;
-        if (a != b) {
-            const TQ qab = Q[(long)a * n + b];
-            v = (float)(qab + Q[(long)b * n + a]);
-            nz = nz || (qab != (TQ)0);        // numpy's (Q - diag(diag(Q))).any()
-        } else {
-            lin[a] = (float)Q[(long)a * n + a];
-        }
-        J[(long)a * n + b] = v;
-        mag[b] = __builtin_fabsf(v);
-    }
-    if (__ballot(nz) != 0ull && lane == 0) atomicOr(any_off, 1);
+    for (int b = lane; b < n; b += 64) mag[b] = __builtin_fabsf(J[(long)a * n + b]);
     __syncthreads();
     if (lane != 0) return;
     row_stats(mag, n, rowabs + a, rowmin + a);
@@ -1175,11 +1191,14 @@ int qbm_qubo_from_Q(const void* Q, int q_is_f64, int n, float* lin, float* J, do
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(any_offdiag, 0, sizeof(int), st);
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(any_offdiag)");
+    const dim3 tiles((n + 63) / 64, (n + 63) / 64);
     if (q_is_f64)
-        hipLaunchKernelGGL((k_qubo_from_Q<double>), dim3(n), dim3(64), 0, st, (const double*)Q, n, lin, J, rowabs, rowmin, any_offdiag);
+        hipLaunchKernelGGL((k_qubo_from_Q<double>), tiles, dim3(256), 0, st, (const double*)Q, n, lin, J, any_offdiag);
     else
-        hipLaunchKernelGGL((k_qubo_from_Q<float>), dim3(n), dim3(64), 0, st, (const float*)Q, n, lin, J, rowabs, rowmin, any_offdiag);
+        hipLaunchKernelGGL((k_qubo_from_Q<float>), tiles, dim3(256), 0, st, (const float*)Q, n, lin, J, any_offdiag);
     QBM_CHECK_LAUNCH("k_qubo_from_Q");
+    hipLaunchKernelGGL(k_qubo_row_stats, dim3(n), dim3(64), 0, st, (const float*)J, n, rowabs, rowmin);
+    QBM_CHECK_LAUNCH("k_qubo_row_stats");
     return QBM_OK;
 }
 

@@ -834,6 +834,45 @@ def _cdqbm_analyse(g, Q, S):
     return E, amo, link
 
 
+def test_qubo_from_Q_bitwise():
+    """qbm_qubo_from_Q (what sample_Q does to its host matrix on the device: include/qbm_hip.h) against numpy, bit for bit:
+    lin = float32(diag), J = float32(off + off.T) in Q's own precision, row sums of |J| (ascending, float64), the smallest
+    non-zero magnitude per row, the "any quadratic term" flag; float64 and float32 matrices, sizes around the 64 x 64 tiles the
+    kernel works in, entries below the diagonal too (the protocol says upper-triangular; the kernel does not rely on it)."""
+    from qbm_image_classification_amd._lib import check, current_stream, ptr
+    from qbm_image_classification_amd.sampler import HipQuboOps
+
+    q = HipQuboOps("cuda:0")
+    rs = np.random.RandomState(21)
+    for n in (1, 2, 63, 64, 65, 130, 257, 717):
+        for dt in (np.float64, np.float32):
+            Q = (rs.standard_normal((n, n)) * (rs.random_sample((n, n)) < 0.3)).astype(dt)
+            if n == 130:
+                Q = np.triu(Q)
+            Qd = torch.from_numpy(Q).cuda()
+            f = lambda *sh, d=torch.float32: torch.empty(*sh, dtype=d, device="cuda")
+            lin, J, ra, rm, flag = f(n), f(n, n), f(n, d=torch.float64), f(n, d=torch.float64), torch.zeros(1, dtype=torch.int32, device="cuda")
+            check(q.lib.qbm_qubo_from_Q(ptr(Qd), int(dt == np.float64), n, ptr(lin), ptr(J), ptr(ra), ptr(rm), ptr(flag), current_stream()),
+                  "qbm_qubo_from_Q")
+            off = Q - np.diag(np.diag(Q))
+            Jw = (off + off.T).astype(np.float32)
+            assert np.array_equal(lin.cpu().numpy(), np.diag(Q).astype(np.float32)) and np.array_equal(J.cpu().numpy(), Jw), (n, dt)
+            mag = np.abs(Jw).astype(np.float64)
+            raw = np.zeros(n)
+            for b in range(n):
+                raw = raw + mag[:, b]                                  # ascending b, one add per term
+            rmw = np.where(mag > 0, mag, np.inf).min(axis=1)
+            rmw[~np.isfinite(rmw)] = 0.0
+            assert np.array_equal(ra.cpu().numpy(), raw) and np.array_equal(rm.cpu().numpy(), rmw), (n, dt)
+            assert int(flag.item()) == int(off.any()), (n, dt)
+    Qz = torch.from_numpy(np.diag(rs.standard_normal(70))).cuda()
+    flag = torch.ones(1, dtype=torch.int32, device="cuda")
+    f = lambda *sh, d=torch.float32: torch.empty(*sh, dtype=d, device="cuda")
+    check(q.lib.qbm_qubo_from_Q(ptr(Qz), 1, 70, ptr(f(70)), ptr(f(70, 70)), ptr(f(70, d=torch.float64)), ptr(f(70, d=torch.float64)), ptr(flag),
+                                current_stream()), "qbm_qubo_from_Q")
+    assert int(flag.item()) == 0
+
+
 def test_sample_q_on_reference_conv_qbm_qubo(oracle):
     """the sample_Q adapter on REAL Conv_Deep_QBM QUBOs -- the penalty-augmented (at-most-one per
     pooling window, OR-link to the pooling unit: src/qubo/builder.py:116-146) clamped / unclamped matrices that
