@@ -278,6 +278,9 @@ __device__ __forceinline__ void gibbs_chain(const float* __restrict__ lin, const
             const bool full = all_full || (JR::kExactTiles && t + 1 < NF);
             unsigned long long want = __ballot(F[t] < thr[t]) ^ sm[t];
             if constexpr (!all_full) want &= pending;
+            // (Reading the row of the NEXT wanting lane while the current flip is applied -- the re-test nearly always confirms it
+            // -- was 45 % SLOWER, 5.21 against 3.60 ms, bit-identical: the loop is bound by the instructions its four wavefronts per
+            // SIMD issue, not by the LDS round trip; profiles/r04_ab_gibbs_flip.jsonl.)
             while (want) {
                 const int l = __builtin_ctzll(want);              // first spin that flips; the ones before it stay
                 // +-1 by the spin's state before the flip: one scalar bit test and select
