@@ -434,7 +434,11 @@ __global__ __launch_bounds__(64) void k_csr_fill(const float* __restrict__ J, in
 constexpr int kCsrMaxWaves = 8;
 constexpr int kCsrLdsBytes = 160 * 1024;
 
-template <int NF>
+// HELP (one chain per workgroup: at most 256 chains, sample_Q's 100 reads): a SECOND wavefront beside the chain's computes the
+// thresholds of sweep s + 1 (Philox, 12 logarithms per lane at n = 717: 3.2 us, an eighth of a sweep) into LDS while the first
+// one walks sweep s -- the chain's wavefront has the CU to itself and nothing else to fill its waits with.  One workgroup barrier
+// per sweep; the same thresholds, the same states.
+template <int NF, bool HELP>
 __global__ __launch_bounds__(64 * kCsrMaxWaves) void k_qubo_gibbs_csr(const float* __restrict__ lin, const CsrHead* __restrict__ head,
                                                                        const int* __restrict__ rowptr, const uint2* __restrict__ ent,
                                                                        int ent_cap /* entries the LDS holds */, int nchains, int R, int n,
@@ -449,9 +453,12 @@ __global__ __launch_bounds__(64 * kCsrMaxWaves) void k_qubo_gibbs_csr(const floa
     for (int i = threadIdx.x; i < nnz; i += blockDim.x) s_ent[i] = ent[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int waves = (int)blockDim.x >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const bool helper = HELP && wv == 1;                  // (HELP: wavefront 0 walks the chain, wavefront 1 prepares its thresholds)
+    const int w = HELP ? 0 : wv;
+    const int waves = HELP ? 1 : (int)blockDim.x >> 6;
     float* Fw = reinterpret_cast<float*>(s_ent + ent_cap) + w * 64 * NF;   // this wavefront's fields
+    float* thb = reinterpret_cast<float*>(s_ent + ent_cap) + 64 * NF;      // HELP: thresholds [2][64 NF], by the sweep's parity
     // lane l: where the entries of the row of spin 64 t + l lie (byte offset in s_ent, 24 bits) and how many (8 bits, 255 = more)
     unsigned rinfo[NF];
 #pragma unroll
@@ -484,7 +491,9 @@ __global__ __launch_bounds__(64 * kCsrMaxWaves) void k_qubo_gibbs_csr(const floa
         // start state s_i = (u < 0.5), draw id `offset` (the draw layout of gibbs_chain: lane l's Philox block 64 pass + l holds the
         // uniforms of its spins in four tiles);  F = lin
         constexpr int NPASS = (NF + 3) / 4;
-        {
+#pragma unroll
+        for (int t = 0; t < NF; ++t) sm[t] = 0ull;
+        if (!helper) {
             f32x4 u0[NPASS];
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) u0[ps] = uniform4(seed, offset, row, (uint32_t)(64 * ps + lane));
@@ -513,7 +522,9 @@ __global__ __launch_bounds__(64 * kCsrMaxWaves) void k_qubo_gibbs_csr(const floa
         }
         const float lr = (sweeps > 1) ? det_logf(b1 / b0) : 0.f;
         float ibv = 0.f;
-        for (int sw = 1; sw <= sweeps; ++sw) {
+        // thresholds of sweep sw (called for sw = 1, 2, ... in order): uniforms as in gibbs_chain (one Philox call per lane and four
+        // tiles); into registers, or (HELP) into the LDS buffer of the sweep's parity
+        auto thresholds = [&](int sw) {
             if (((sw - 1) & 63) == 0) {   // (as in gibbs_chain: lane L holds 1 / beta of sweep sw + L)
                 const int s2 = sw + lane;
                 float bt = b1;
@@ -521,7 +532,6 @@ __global__ __launch_bounds__(64 * kCsrMaxWaves) void k_qubo_gibbs_csr(const floa
                 ibv = 1.0f / bt;
             }
             const float ib = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ibv), (sw - 1) & 63));
-            // uniforms and thresholds of this sweep: as in gibbs_chain (one Philox call per lane and four tiles)
             f32x4 ub[NPASS];
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps)
@@ -529,8 +539,27 @@ __global__ __launch_bounds__(64 * kCsrMaxWaves) void k_qubo_gibbs_csr(const floa
 #pragma unroll
             for (int t = 0; t < NF; ++t) {
                 const int i = 64 * t + lane;
-                thr[t] = (i < n) ? neg_logit(ub[t >> 2][t & 3]) * ib : 0.f;
+                const float th = (i < n) ? neg_logit(ub[t >> 2][t & 3]) * ib : 0.f;
+                if constexpr (HELP) thb[(sw & 1) * 64 * NF + i] = th;
+                else thr[t] = th;
             }
+        };
+        if constexpr (HELP) {
+            if (helper && sweeps >= 1) thresholds(1);
+            __syncthreads();
+        }
+        for (int sw = 1; sw <= sweeps; ++sw) {
+            if constexpr (HELP) {
+                if (helper) {
+                    if (sw < sweeps) thresholds(sw + 1);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NF; ++t) thr[t] = thb[(sw & 1) * 64 * NF + 64 * t + lane];
+                }
+            } else {
+                thresholds(sw);
+            }
+            if (!helper) {
 #pragma unroll
             for (int t = 0; t < NF; ++t) {
                 const int cnt = min(64, n - 64 * t);
@@ -563,11 +592,15 @@ __global__ __launch_bounds__(64 * kCsrMaxWaves) void k_qubo_gibbs_csr(const floa
                     want = (__ballot(*Ft < thr[t]) ^ sm[t]) & tile & ((~0ull << l) << 1);
                 }
             }
+            }
+            if constexpr (HELP) __syncthreads();   // sweep sw walked, the thresholds of sweep sw + 1 written
         }
+        if (!helper) {
 #pragma unroll
-        for (int t = 0; t < NF; ++t) {
-            const int i = 64 * t + lane;
-            if (i < n) states[(long)ch * n + i] = (uint8_t)((sm[t] >> lane) & 1ull);
+            for (int t = 0; t < NF; ++t) {
+                const int i = 64 * t + lane;
+                if (i < n) states[(long)ch * n + i] = (uint8_t)((sm[t] >> lane) & 1ull);
+            }
         }
     }
 }
@@ -1008,7 +1041,8 @@ inline CsrLayout csr_layout(int n, long cap)
 // wavefronts per workgroup and the entries the LDS then holds
 inline int csr_waves(int nch) { const int w = (nch + 255) / 256; return w < 1 ? 1 : w > kCsrMaxWaves ? kCsrMaxWaves : w; }
 inline int csr_nf(int n) { const int NF = (n + 63) / 64; return NF <= 6 ? 6 : NF <= 8 ? 8 : NF <= 10 ? 10 : NF <= 12 ? 12 : 16; }
-inline long csr_lds_cap(int n, int waves) { return ((long)kCsrLdsBytes - 256 - (long)waves * 256 * csr_nf(n)) / 8; }
+// (one chain per workgroup: + two threshold buffers for the helper wavefront, k_qubo_gibbs_csr<NF, true>)
+inline long csr_lds_cap(int n, int waves) { return ((long)kCsrLdsBytes - 256 - (long)(waves == 1 ? 3 : waves) * 256 * csr_nf(n)) / 8; }
 
 template <int NF>
 int launch_gibbs_csr(const float* lin, const char* ws, int cap, int B, int R, int n, int sweeps, float beta0, float beta1,
@@ -1016,20 +1050,25 @@ int launch_gibbs_csr(const float* lin, const char* ws, int cap, int B, int R, in
 {
     const int nch = B * R;
     const int waves = csr_waves(nch);
+    const bool help = waves == 1;                        // one chain per workgroup: a second wavefront prepares its thresholds
     const long lds_cap = csr_lds_cap(n, waves);
     const int ent_cap = (int)(cap < lds_cap ? cap : lds_cap);
-    const size_t lds = (size_t)ent_cap * 8 + (size_t)waves * 256 * NF;
+    const size_t lds = (size_t)ent_cap * 8 + (size_t)(help ? 3 : waves) * 256 * NF;
     const CsrLayout L = csr_layout(n, cap);
+    const void* fn = help ? reinterpret_cast<const void*>(k_qubo_gibbs_csr<NF, true>) : reinterpret_cast<const void*>(k_qubo_gibbs_csr<NF, false>);
     if (lds > 65536) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_qubo_gibbs_csr<NF>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(k_qubo_gibbs_csr)");
     }
     int wgs = (nch + waves - 1) / waves;
     if (wgs > 256) wgs = 256;
-    hipLaunchKernelGGL((k_qubo_gibbs_csr<NF>), dim3(wgs), dim3(64 * waves), lds, st, lin, (const CsrHead*)ws,
-                       (const int*)(ws + L.rowptr), (const uint2*)(ws + L.ent), ent_cap, nch, R, n, sweeps, beta0, beta1, beta_dev,
-                       seed, offset, chain0, states);
+    if (help)
+        hipLaunchKernelGGL((k_qubo_gibbs_csr<NF, true>), dim3(wgs), dim3(128), lds, st, lin, (const CsrHead*)ws, (const int*)(ws + L.rowptr),
+                           (const uint2*)(ws + L.ent), ent_cap, nch, R, n, sweeps, beta0, beta1, beta_dev, seed, offset, chain0, states);
+    else
+        hipLaunchKernelGGL((k_qubo_gibbs_csr<NF, false>), dim3(wgs), dim3(64 * waves), lds, st, lin, (const CsrHead*)ws,
+                           (const int*)(ws + L.rowptr), (const uint2*)(ws + L.ent), ent_cap, nch, R, n, sweeps, beta0, beta1, beta_dev,
+                           seed, offset, chain0, states);
     QBM_CHECK_LAUNCH("k_qubo_gibbs_csr");
     return QBM_OK;
 }
