@@ -548,7 +548,11 @@ def test_qubo_gibbs_csr_bitwise(oracle):
                                                         (1, 100, 717, 8, 40, 3, 0.2, 2.5, 0), (3, 200, 520, 10, 70, 2, 0.5, 1.5, 0),
                                                         (1, 9, 1024, 12, 200, 2, 1.0, 1.0, 0), (2, 6, 60, 4, 30, 5, 0.4, 2.0, 0),
                                                         (30, 100, 330, 6, None, 2, 0.3, 2.0, 0), (2, 33, 650, 8, 65, 3, 0.3, 2.0, 17),
-                                                        (1, 12, 897, 8, None, 2, 0.5, 1.5, 0)]:
+                                                        (1, 12, 897, 8, None, 2, 0.5, 1.5, 0),
+                                                        # no sweep at all / one sweep (the helper wavefront's first and only buffer),
+                                                        # 256 chains (one per workgroup, with the helper) and 257 (two per workgroup)
+                                                        (1, 7, 300, 8, None, 0, 0.5, 1.5, 0), (1, 7, 300, 8, None, 1, 0.5, 1.5, 0),
+                                                        (256, 1, 290, 6, None, 3, 0.4, 2.0, 0), (257, 1, 290, 6, None, 3, 0.4, 2.0, 0)]:
         lin = rs.standard_normal((B, n)).astype(np.float32)
         J = _sparse_qubo(rs, n, deg, hub=hub)
         J[5, :] = 0
