@@ -129,7 +129,8 @@ __global__ __launch_bounds__(KC_THREADS) void k_kc_step(const float* __restrict_
 //     until all carry the round: the barrier IS the data (0.3 us, tools/microbench/xcd_barrier.hip);
 //   * across XCDs: the leader publishes the XCD's best as one `sc1` (write-through) 8-byte store on a line of its own and
 //     polls the 8 lines with `sc1` loads (a data-tagged granule: no fence, no ordering needed; MI355X_MICROARCH.md
-//     "handoff-1to1": ~1 us), then hands the winner to its XCD through the L2 again; the other workgroups poll that word;
+//     "handoff-1to1": ~1 us); the other workgroups of the chip poll the same 8 lines themselves (the leader handing the
+//     winner back through its XCD's L2 -- one more hop for 8 pollers instead of 256 -- was 0.35 us per pick slower);
 //   * the new centre's coordinates are read from the row-major matrix (1 KB, contiguous).
 // Measured at 12 665 x 256, 1000 picks: 5.5 us per pick with every workgroup polling both levels (the first version);
 // 7.0 us with a FLAT exchange (every workgroup publishes write-through and polls all 256 granules: one hop instead of two,
@@ -151,7 +152,7 @@ struct KfCtl {                         // zeroed by the host before the launch
     // with everybody's round-(r + 1) granule, which a workgroup stores after it has finished round r).
     unsigned long long xc[2][8][64];   // per XCD: one granule per workgroup (plain stores, sc1 polls: XCD-local)
     unsigned long long gc[2][8][16];   // per XCD: its best, word 0 of a 128-byte line of its own (sc1 store, sc1 polls)
-    unsigned long long win[2][8][16];  // per XCD: the chip's best, handed to the XCD by its leader (plain store, sc1 polls)
+    unsigned long long win[2][8][16];  // (unused since every workgroup polls gc itself; kept: the workspace size is part of the ABI)
 };
 __device__ __forceinline__ unsigned long long kf_pack(float v, int idx, uint32_t round)
 {
@@ -331,16 +332,26 @@ __global__ __launch_bounds__(KF_THREADS) void k_kc_fused(const float* __restrict
                     const int oi = __shfl_xor(idx, off, kWave);
                     if (better(ov, oi, v, idx)) { v = ov; idx = oi; }
                 }
-                if (ok && lane == 0) __hip_atomic_store(&ctl->win[par][x][0], kf_pack(v, idx, round), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            } else {
-                for (int spins = 0;; ++spins) {
-                    gr = __hip_atomic_load(&ctl->win[par][x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (one address: a broadcast load)
-                    if ((gr & 0xffull) == tag) break;
-                    // the leader may have given up (or some other workgroup of the chip): stop polling then
+            }
+            else {
+                // every other workgroup polls the 8 XCDs' granules ITSELF: the leader handing the winner back through the XCD's L2 (one
+                // more hop, 8 pollers instead of 256 on the 8 lines) was 0.35 us per pick slower (4.85 against 4.5, alternating runs)
+                const bool live = lane < 8 && s_cnt[lane & 7] > 0u;
+                for (int spins = 0; ok; ++spins) {
+                    gr = live ? __hip_atomic_load(&ctl->gc[par][lane & 7][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (unsigned long long)tag;
+                    if (__all((int)((gr & 0xffull) == tag))) break;
                     if ((spins & 255) == 255 && __hip_atomic_load(&ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
-                    if (spins > KF_SPIN) { ok = false; break; }
+                    if (spins > KF_SPIN) ok = false;
                 }
-                kf_unpack(gr, v, idx);
+                v = -__builtin_inff();
+                idx = 0xffffff;
+                if (live) kf_unpack(gr, v, idx);
+#pragma unroll
+                for (int off = 4; off >= 1; off >>= 1) {
+                    const float ov = __shfl_xor(v, off, kWave);
+                    const int oi = __shfl_xor(idx, off, kWave);
+                    if (better(ov, oi, v, idx)) { v = ov; idx = oi; }
+                }
             }
             if (lane == 0) {
                 if (!ok) __hip_atomic_store(&ctl->status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
