@@ -914,13 +914,72 @@ __global__ __launch_bounds__(64) void k_qbm_beta(const float* __restrict__ lin, 
 // Both phases' statistics (get_average_configuration_batch, :754-848) and their difference in one pass:
 // diff = stat(clamped means) - stat(unclamped means), each accumulated sequentially over the images like k_batch_stats
 // (same element order: W_vh | W_vo | b_h | b_o).
+// The weight block -- (1 + D) x H elements, each a sum over the B images of x_ik * mean_ij -- in tiles of kSdKB rows x 256
+// columns per workgroup (round 4): a thread keeps kSdKB pairs of sums in registers and reads its column's two means ONCE per
+// image; the pixels of the tile's rows pass through LDS.  One thread per element, as until then, read both means again for
+// every one of the 785 rows: 235 MB through the L2 for 150 KB of means, 27-35 us of a launch that computes for 2.  Same terms,
+// same order (images ascending, product then sum).  Workgroups behind the tiles take the remaining D + H + 1 (+ 1) elements.
+constexpr int kSdKB = 4, kSdIm = 128;
 __global__ __launch_bounds__(256) void k_qbm_stats_diff(const double* __restrict__ X, const int* __restrict__ labels,
                                                         const double* __restrict__ mean_c /* [B,H] */,
                                                         const double* __restrict__ mean_u /* [B,1+H] */, int B, int D,
-                                                        int H, double* __restrict__ diff, int with_nll)
+                                                        int H, double* __restrict__ diff, int with_nll, int n_tiles, int n_jb)
 {
     const long nW = (long)(1 + D) * H;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nu = H + 1;
+    if ((int)blockIdx.x < n_tiles) {
+        __shared__ double xs[kSdIm][kSdKB];
+        const int tid = threadIdx.x;
+        const int jb = (int)blockIdx.x % n_jb, kb = (int)blockIdx.x / n_jb;
+        const int j = 256 * jb + tid, k0 = kSdKB * kb;     // rows k0 .. k0 + kSdKB - 1 (row D: the label row, clamped phase only)
+        double c[kSdKB], u[kSdKB];
+#pragma unroll
+        for (int q = 0; q < kSdKB; ++q) c[q] = u[q] = 0.0;
+        for (int i0 = 0; i0 < B; i0 += kSdIm) {
+            const int nb = min(kSdIm, B - i0);
+            __syncthreads();
+            for (int e = tid; e < nb * kSdKB; e += 256) {
+                const int ii = e / kSdKB, q = e % kSdKB, k = k0 + q;
+                xs[ii][q] = k < D ? X[(long)(i0 + ii) * D + k] : (k == D ? (double)labels[i0 + ii] : 0.0);
+            }
+            __syncthreads();
+            if (j < H) {
+                int ii = 0;
+                for (; ii + 4 <= nb; ii += 4) {           // (the means of 4 images requested together)
+                    double mc[4], mu[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        mc[r] = mean_c[(long)(i0 + ii + r) * H + j];
+                        mu[r] = mean_u[(long)(i0 + ii + r) * nu + 1 + j];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int q = 0; q < kSdKB; ++q) {
+                            const double x = xs[ii + r][q];
+                            c[q] += x * mc[r];
+                            if (k0 + q < D) u[q] += x * mu[r];
+                        }
+                }
+                for (; ii < nb; ++ii) {
+                    const double mc = mean_c[(long)(i0 + ii) * H + j], mu = mean_u[(long)(i0 + ii) * nu + 1 + j];
+#pragma unroll
+                    for (int q = 0; q < kSdKB; ++q) {
+                        const double x = xs[ii][q];
+                        c[q] += x * mc;
+                        if (k0 + q < D) u[q] += x * mu;
+                    }
+                }
+            }
+        }
+        if (j < H) {
+#pragma unroll
+            for (int q = 0; q < kSdKB; ++q)
+                if (k0 + q <= D) diff[(long)(k0 + q) * H + j] = c[q] - u[q];
+        }
+        return;
+    }
+    const long idx = nW + (long)((int)blockIdx.x - n_tiles) * blockDim.x + threadIdx.x;
     if (with_nll && idx == nW + D + H + 1) {
         // diff[theta length] = sum over the images of compute_nll's term (src/model/faster_dqbm.py:986-991):
         // -log(float32([1 - p1, p1])[y] + 1e-12), p1 = mean of the output node; float32 terms, float64 sum in image order
@@ -935,37 +994,8 @@ __global__ __launch_bounds__(256) void k_qbm_stats_diff(const double* __restrict
         return;
     }
     if (idx >= nW + D + H + 1) return;
-    const int nu = H + 1;
     double c = 0.0, u = 0.0;
-    if (idx < nW) {
-        const int k = (int)(idx / H), j = (int)(idx % H);
-        if (k < D) {
-            // (the operands of 8 images requested together: the sums are two chains of B dependent float64 operations, the
-            // loads do not depend on them)
-            int i = 0;
-            for (; i + 8 <= B; i += 8) {
-                double x[8], mc[8], mu[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    x[q] = X[(long)(i + q) * D + k];
-                    mc[q] = mean_c[(long)(i + q) * H + j];
-                    mu[q] = mean_u[(long)(i + q) * nu + 1 + j];
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    c += x[q] * mc[q];
-                    u += x[q] * mu[q];
-                }
-            }
-            for (; i < B; ++i) {
-                const double x = X[(long)i * D + k];
-                c += x * mean_c[(long)i * H + j];
-                u += x * mean_u[(long)i * nu + 1 + j];
-            }
-        } else {
-            for (int i = 0; i < B; ++i) c += (double)labels[i] * mean_c[(long)i * H + j];   // label row: clamped phase only
-        }
-    } else if (idx < nW + D) {
+    if (idx < nW + D) {
         const int k = (int)(idx - nW);
         for (int i = 0; i < B; ++i) {
             const double x = X[(long)i * D + k];
@@ -1270,9 +1300,10 @@ int qbm_qbm_stats_diff(const double* X, const int32_t* labels, const double* mea
     if (B < 0) return fail(QBM_ERR_ARG, "stats_diff: B < 0");
     if (D <= 0 || H <= 0) return fail(QBM_ERR_ARG, "stats_diff: non-positive dims");
     if (!diff || (B > 0 && (!X || !labels || !mean_c || !mean_u))) return fail(QBM_ERR_ARG, "stats_diff: null buffer");
-    const long total = qbm_theta_len(D, H);
-    hipLaunchKernelGGL(k_qbm_stats_diff, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, labels,
-                       mean_c, mean_u, B, D, H, diff, 0);
+    const int n_jb = (H + 255) / 256, n_tiles = n_jb * ((D + 1 + kSdKB - 1) / kSdKB);
+    const int n_tail = (D + H + 1 + 255) / 256;
+    hipLaunchKernelGGL(k_qbm_stats_diff, dim3((unsigned)(n_tiles + n_tail)), dim3(256), 0, (hipStream_t)stream, X, labels,
+                       mean_c, mean_u, B, D, H, diff, 0, n_tiles, n_jb);
     QBM_CHECK_LAUNCH("k_qbm_stats_diff");
     return QBM_OK;
 }
@@ -1283,9 +1314,10 @@ int qbm_qbm_stats_diff_nll(const double* X, const int32_t* labels, const double*
     if (B < 0) return fail(QBM_ERR_ARG, "stats_diff_nll: B < 0");
     if (D <= 0 || H <= 0) return fail(QBM_ERR_ARG, "stats_diff_nll: non-positive dims");
     if (!diff || (B > 0 && (!X || !labels || !mean_c || !mean_u))) return fail(QBM_ERR_ARG, "stats_diff_nll: null buffer");
-    const long total = qbm_theta_len(D, H) + 1;
-    hipLaunchKernelGGL(k_qbm_stats_diff, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, labels,
-                       mean_c, mean_u, B, D, H, diff, 1);
+    const int n_jb = (H + 255) / 256, n_tiles = n_jb * ((D + 1 + kSdKB - 1) / kSdKB);
+    const int n_tail = (D + H + 2 + 255) / 256;
+    hipLaunchKernelGGL(k_qbm_stats_diff, dim3((unsigned)(n_tiles + n_tail)), dim3(256), 0, (hipStream_t)stream, X, labels,
+                       mean_c, mean_u, B, D, H, diff, 1, n_tiles, n_jb);
     QBM_CHECK_LAUNCH("k_qbm_stats_diff");
     return QBM_OK;
 }

@@ -743,7 +743,9 @@ def test_qbm_device_state_kernels_bitwise(oracle):
 
     q = HipQuboOps("cuda:0")
     rs = np.random.RandomState(21)
-    for D, H, B, restricted, beta_eff in ((12, 5, 4, False, 0.7), (784, 256, 73, False, 1.0), (784, 33, 9, True, 2.0)):
+    # (the statistics kernel works in tiles of 4 rows x 256 columns and chunks of 128 images: shapes on both sides of each)
+    for D, H, B, restricted, beta_eff in ((12, 5, 4, False, 0.7), (784, 256, 73, False, 1.0), (784, 33, 9, True, 2.0), (7, 300, 131, False, 1.0),
+                                          (3, 256, 128, False, 0.5), (9, 257, 1, True, 1.0)):
         n_theta = (1 + D) * H + D + H + 1
         theta = rs.uniform(-1, 1, n_theta)
         W_hh = None if restricted else np.triu(rs.uniform(-1, 1, (H, H)), 1)
